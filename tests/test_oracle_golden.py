@@ -1,0 +1,154 @@
+"""The CPU oracle against the reference's outputs (tests/golden/*.npz, made by make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_params as gp
+from oracle import fdconv_ref as fr
+from oracle import realesrganer_ref as rr
+from oracle.rrdbnet_ref import rrdbnet_forward
+
+FP32_TOL = 1e-4  # north_star: fp32 max-abs-err <= 1e-4
+
+
+def t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def test_base_masks_match_reference_buffer(golden):
+    rows, cols = fr.fbm_base_masks()
+    ref = torch.from_numpy(golden['fdconv_layers']['cached_masks'])[:, 0]  # (3,64,33)
+    assert torch.equal(rows[:, :, None] & cols[:, None, :], ref)
+    # the sets SURVEY 8(a8) lists: strict cut for k=2, inclusive for k=4,8
+    assert rows[0].nonzero().flatten().tolist() == list(range(16)) + list(range(49, 64))
+    assert rows[1].nonzero().flatten().tolist() == list(range(9)) + list(range(56, 64))
+    assert rows[2].nonzero().flatten().tolist() == list(range(5)) + list(range(60, 64))
+    assert [int(c.sum()) for c in cols] == [16, 9, 5]
+
+
+def test_resized_masks(golden):
+    g = golden['fbm_masks']
+    for key in g.files:
+        if not key.startswith('rows_'):
+            continue
+        n = int(key[5:])
+        rm, cm = fr.fbm_masks(n, n)
+        assert np.array_equal(rm.numpy(), g['rows_%d' % n]), n
+        assert np.array_equal(cm.numpy(), g['cols_%d' % n]), n
+
+
+def test_nearest_index_matches_torch():
+    for n in list(range(1, 300)) + [511, 522, 532, 1044, 2088, 2128, 4096]:
+        src = torch.arange(64, dtype=torch.float32).view(1, 1, 64)
+        got = torch.nn.functional.interpolate(src, size=n, mode='nearest').flatten().long()
+        assert torch.equal(got, fr.nearest_src_index(n, 64)), n
+
+
+def test_group_maps(golden):
+    for cin, cout in gp.LAYER_SHAPES:
+        ref = golden['group_maps']['gmap_%d_%d' % (cin, cout)]
+        got = fr.freq_group_map(cout, cin).numpy()
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), (cin, cout)
+        assert np.bincount(got.ravel()).tolist() == [got.size // 4] * 4
+
+
+def _cases(golden):
+    out = []
+    for key in golden['fdconv_layers'].files:
+        if key.startswith('c') and key.endswith('.y'):
+            tag = key[:-2]
+            cin, cout, h, w = [int(s.lstrip('chw')) for s in tag.split('_')]
+            out.append((tag, cin, cout, h, w))
+    return out
+
+
+def test_fdconv_layers_eval(golden):
+    g = golden['fdconv_layers']
+    cases = _cases(golden)
+    assert len(cases) >= 10
+    for tag, cin, cout, h, w in cases:
+        li = gp.LAYER_SHAPES.index((cin, cout))
+        sd = t(gp.fdconv_params(cin, cout, seed=100 + li))
+        x = torch.from_numpy(gp.signed_input((2, cin, h, w), seed=200 + li))
+        want = {}
+        y = fr.fdconv_forward(x, sd, want=want)
+        for k in ('ca', 'fa', 'sa', 'ka'):
+            assert np.abs(want[k].numpy() - g[tag + '.' + k]).max() < 1e-5, (tag, k)
+        if tag + '.fbm' in g.files:
+            assert np.abs(want['fbm'].numpy() - g[tag + '.fbm']).max() < 2e-5, tag
+        err = np.abs(y.numpy() - g[tag + '.y']).max()
+        assert err < FP32_TOL, (tag, err)
+
+
+def test_fdconv_fp64_oracle_brackets_reference(golden):
+    """An fp64 evaluation of the oracle is as close to the fp32 reference as fp32 noise allows."""
+    g = golden['fdconv_layers']
+    sd = t(gp.fdconv_params(64, 32, seed=100))
+    x = torch.from_numpy(gp.signed_input((2, 64, 40, 48), seed=200))
+    y = fr.fdconv_forward(x, sd, dtype=torch.float64)
+    assert np.abs(y.numpy() - g['c64_32_h40_w48.y']).max() < FP32_TOL
+
+
+def test_fdconv_train_mode(golden):
+    sd = t(gp.fdconv_params(64, 32, seed=100))
+    x = torch.from_numpy(gp.signed_input((4, 64, 20, 24), seed=300))
+    y = fr.fdconv_forward(x, sd, training=True)
+    assert np.abs(y.numpy() - golden['fdconv_layers']['train_c64_32.y']).max() < FP32_TOL
+
+
+def test_rrdbnet_fdconv_one_block(golden):
+    sd = t(gp.rrdbnet_state(1, 1, 64, 1, 32, seed=7))
+    assert len(sd) == int(golden['rrdbnet_fdconv_1block']['n_keys'])
+    x = torch.from_numpy(gp.image_input((2, 1, 32, 32), seed=70))
+    y = rrdbnet_forward(sd, x)
+    ref = golden['rrdbnet_fdconv_1block']['y']
+    assert y.shape == (2, 1, 128, 128)
+    err = np.abs(y.numpy() - ref).max()
+    assert err < FP32_TOL * max(1.0, np.abs(ref).max()), err
+
+
+def test_realesrganer_geometry(golden):
+    g = golden['realesrganer']
+    sd = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=9, fdconv=False))
+    net = lambda z: rrdbnet_forward(sd, z)
+    img = gp.image_input((50, 70, 3), seed=90)
+    for tag, tile, pad, pre in (('whole', 0, 10, 0), ('tile32', 32, 10, 0), ('tile32_pre7', 32, 10, 7), ('tile16_pad4', 16, 4, 3)):
+        out = rr.run_rgb(net, img, 4, tile, pad, pre).numpy()
+        ref = g['rgb50x70_' + tag]
+        assert out.shape == ref.shape == (1, 3, 200, 280)
+        assert np.abs(out - ref).max() < 1e-5, tag
+    # Real-ESRGAN-master/tests/test_utils.py:33-56 shapes
+    img12 = gp.image_input((12, 12, 3), seed=91)
+    assert tuple(g['t_pre_shape']) == tuple(rr.pre_process(img12, 4, 2)[0].shape) == (1, 3, 14, 14)
+    pm, mh, mw, ms = rr.pre_process(img12, 1, 2)
+    assert tuple(pm.shape) == tuple(g['t_pre_mod_shape']) == (1, 3, 16, 16) and (mh, mw, ms) == (2, 2, 4)
+    assert np.array_equal(pm.numpy(), g['t_pre_mod_img'])
+    # the reference object keeps mod_scale=4 from the scale=1 call (test_utils.py:38-56), so the
+    # tiled run sees the 16x16 mod-padded image
+    out = rr.tile_process(net, pm, 4, 10, 10)
+    assert tuple(out.shape) == tuple(g['t_tile_shape']) == (1, 3, 64, 64)
+    assert np.abs(out.numpy() - g['t_tile_out']).max() < 1e-5
+
+
+def test_realesrganer_scale2(golden):
+    sd = t(gp.rrdbnet_state(12, 3, 8, 1, 4, seed=10, fdconv=False))
+    net = lambda z: rrdbnet_forward(sd, z, scale=2)
+    img = gp.image_input((21, 33, 3), seed=92)
+    out = rr.run_rgb(net, img, 2, 0, 10, 0).numpy()
+    ref = golden['realesrganer']['x2_21x33']
+    assert out.shape == ref.shape == (1, 3, 42, 66)
+    assert np.abs(out - ref).max() < 1e-5
+
+
+def test_enhance_modes():
+    sd = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=9, fdconv=False))
+    net = lambda z: rrdbnet_forward(sd, z)
+    o, m = rr.enhance(net, (gp.image_input((6, 5, 3), 1) * 255).astype(np.uint8), 4, pre_pad=2)
+    assert o.shape == (24, 20, 3) and o.dtype == np.uint8 and m == 'RGB'
+    o, m = rr.enhance(net, (gp.image_input((6, 5), 2) * 60000).astype(np.uint16), 4, pre_pad=2)
+    assert o.shape == (24, 20) and o.dtype == np.uint16 and m == 'L'
+    o, m = rr.enhance(net, gp.image_input((6, 5, 4), 3), 4, pre_pad=0, tile=4, tile_pad=2)
+    assert o.shape == (24, 20, 4) and m == 'RGBA'
+    o, m = rr.enhance(net, gp.image_input((6, 5, 4), 3), 4, pre_pad=0, alpha_upsampler=None)
+    assert o.shape == (24, 20, 4) and m == 'RGBA'
