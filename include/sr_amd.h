@@ -1,0 +1,178 @@
+/*
+ * sr_amd.h -- C ABI of libsr_amd.so: the MI355X (gfx950) kernels under the RRDBNet / FDConv /
+ * RealESRGANer Python API of cdrookie/Super_resolution.
+ *
+ * The reference has no FFI on this path: it is Python on torch operators.  Each entry point
+ * below therefore names the torch call (reference file:line) whose work it takes over.  Paths
+ * are relative to /root/reference; "FDConv.py" is
+ * FDConv-main/FDConv-main/FDConv_detection/mmdet_custom/FDConv.py and "RRDBNet" is
+ * basicsr==1.4.2 basicsr/archs/rrdbnet_arch.py (not vendored; call site
+ * train/train_realESRGAN_fdconv_1.py:100).
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory on the current HIP device unless it says "host";
+ *   - activations are NHWC ("pixel-major, channels innermost") in `dtype` (SR_F32 or SR_BF16):
+ *     element (b,h,w,c) of a tensor view lives at ((b*H + h)*W + w)*ld + c0 + c;
+ *   - no entry point allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*); scratch memory is supplied by the caller;
+ *     the exceptions are the *_create / *_destroy pairs which build small lookup tables;
+ *   - return value: 0 = SR_OK, negative = error (see sr_strerror); nothing is launched on error.
+ */
+#ifndef SR_AMD_H
+#define SR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_ERR_ARG (-1)       /* bad argument / unsupported shape */
+#define SR_ERR_WORKSPACE (-2) /* caller's scratch buffer too small */
+#define SR_ERR_HIP (-3)       /* a HIP runtime call failed (see sr_last_hip_error) */
+#define SR_ERR_STATE (-4)     /* object not prepared for this shape */
+
+#define SR_F32 0
+#define SR_BF16 1
+
+#define SR_MAX_SEG 8 /* max tensors in a virtual channel concat */
+
+/* A view of `C` channels of an NHWC tensor whose pixels are `ld` elements apart. */
+typedef struct {
+    void* p;     /* base of the underlying tensor */
+    int32_t ld;  /* elements per pixel in the underlying tensor */
+    int32_t c0;  /* first channel of the view */
+    int32_t C;   /* channels in the view */
+    int32_t _pad;
+} sr_view;
+
+/* The input of a conv: a virtual concat (torch.cat in RRDBNet's dense block) of up to
+ * SR_MAX_SEG views.  When `bands` is set every view also has its three FBM low-pass planes
+ * (same shape, at the conv's resolution).  `ups` = 1 reads x through a nearest 2x upsample
+ * (F.interpolate(scale_factor=2, mode='nearest') in RRDBNet.forward): x is then (H/2, W/2). */
+typedef struct {
+    int32_t nseg;
+    int32_t bands;
+    int32_t ups;
+    int32_t _pad;
+    sr_view x[SR_MAX_SEG];
+    sr_view l2[SR_MAX_SEG];
+    sr_view l4[SR_MAX_SEG];
+    sr_view l8[SR_MAX_SEG];
+} sr_concat;
+
+/* Epilogue of a conv:  y = acc + bias ; lrelu ? leaky_relu(y, 0.2) ; y = y*s1 + r1 ; y = y*s2 + r2
+ * (RRDBNet: lrelu(conv(x)); ResidualDenseBlock x5*0.2+x; RRDB out*0.2+x; feat + body_feat). */
+typedef struct {
+    const float* bias; /* [Cout] or NULL */
+    int32_t lrelu;
+    int32_t _pad;
+    sr_view r1;  /* p == NULL: unused */
+    float s1;
+    float _pad1;
+    sr_view r2;
+    float s2;
+    float _pad2;
+} sr_epilogue;
+
+/* Parameters of one conv layer of RRDBNet, as float32 device pointers straight into the
+ * nn.Module's parameter storage (state_dict layout of SURVEY 8b), plus two derived buffers. */
+typedef struct {
+    int32_t cin, cout;
+    int32_t active;   /* 1: FDConv path (has dft_weight); 0: plain nn.Conv2d (FDConv.py:641-642) */
+    int32_t loc_taps; /* KSM_Local.conv kernel size (FDConv.py:282) */
+    const float* bias;     /* (cout) or NULL */
+    const void* wpacked;   /* plain: weight repacked by sr_pack_conv_weight to [9][cout][cin] in dtype */
+    const float* basis;    /* active: sr_fdconv_basis output [4][cout][cin][9] */
+    const float* fc_w;     /* KSM_Global.fc.weight (16,cin) */
+    const float *bn_w, *bn_b, *bn_rm, *bn_rv; /* KSM_Global.bn.* (16) */
+    const float *relu_s, *relu_b;             /* KSM_Global.relu.{scale,bias} (1) */
+    const float *ch_w, *ch_b;                 /* channel_fc (cin,16),(cin) */
+    const float *fl_w, *fl_b;                 /* filter_fc  (cout,16),(cout) */
+    const float *sp_w, *sp_b;                 /* spatial_fc (9,16),(9) */
+    const float *kn_w, *kn_b;                 /* kernel_fc  (4,16),(4) */
+    const float* gate_w[3];                   /* FBM.freq_weight_conv_list.k.weight (1,cin,3,3) */
+    const float* gate_b[3];                   /* ....bias (1) */
+    const float* loc_w;                       /* KSM_Local.conv.weight (cout*9,1,taps) */
+    const float *ln_w, *ln_b;                 /* KSM_Local.norm.{weight,bias} (cin) */
+} sr_layer_params;
+
+const char* sr_strerror(int code);
+int sr_last_hip_error(void); /* hipError_t of the last failed HIP call on this thread */
+int sr_version(void);
+
+/* ---- layout ------------------------------------------------------------------------------
+ * NCHW (torch default) <-> NHWC.  pack folds basicsr's pixel_unshuffle(x, r) (RRDBNet.forward,
+ * scale 2 -> r=2, scale 1 -> r=4; r=1: none): dst is (B, H/r, W/r, C*r*r), channel c*r*r+dy*r+dx. */
+int sr_pack_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W, int r,
+                 void* stream);
+int sr_unpack_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W,
+                   void* stream);
+/* nn.Conv2d weight (cout,cin,3,3) f32 -> [9][cout][cin] in `dtype` (what the conv kernels read) */
+int sr_pack_conv_weight(const float* w, void* dst, int dtype, int cout, int cin, void* stream);
+
+/* ---- FBM low-pass (FDConv.py:427-457: rfft2 -> 3 box masks -> irfft2) ----------------------
+ * A plan holds the twiddles, the nearest-resized masks (F.interpolate at FDConv.py:446) and the
+ * kept-column lists for one (H, W).  create/destroy allocate; everything else does not. */
+typedef struct sr_fbm_plan sr_fbm_plan;
+int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out);
+void sr_fbm_plan_destroy(sr_fbm_plan* plan);
+/* host-only (no HIP call): the resized masks as HOST arrays rows (3*H bytes), cols (3*(W/2+1) bytes) */
+int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host);
+size_t sr_fbm_workspace_bytes(const sr_fbm_plan* plan, int B, int C);
+/* x: (B,H,W,C) view, or (B,H/2,W/2,C) when ups=1.  Writes L_k = lowpass_k(x) for k=2,4,8 into
+ * l2/l4/l8 (B,H,W,C) and, if pooled != NULL, the spatial mean of every channel
+ * (F.adaptive_avg_pool2d at FDConv.py:643) into pooled[b*pooled_ld + c] (float). */
+int sr_fbm_lowpass(const sr_fbm_plan* plan, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4, sr_view l8,
+                   float* pooled, int pooled_ld, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- FBM gates (FDConv.py:460-461): g_k = 2*sigmoid(conv3x3(x; gate_w[k]) + gate_b[k]) ------
+ * gates: float (B,H,W,4) = {g1,g2,g3,unused}. */
+int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in, const sr_layer_params* lp, float* gates,
+                 void* stream);
+
+/* ---- FDConv weight path --------------------------------------------------------------------
+ * basis: the inverse real 2-D DFT (torch.fft.irfft2 at FDConv.py:683) of the alpha-scaled
+ * spectrum restricted to each of the 4 frequency groups (FDConv.py:661-680), rearranged to
+ * [4][cout][cin][3*3].  gmap: uint8 (3cout, 3cin/2+1) group ids.  Run when dft_weight changes. */
+size_t sr_fdconv_basis_workspace_bytes(int cout, int cin);
+int sr_fdconv_basis(const float* dft_weight, const uint8_t* gmap, float alpha, int cout, int cin, float* basis,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* per-sample weights W_b = sa*ca*fa*hr*sum_g ka_g*basis_g (FDConv.py:644-652,692-697) from the
+ * pooled means (B, pooled_ld) -> wdyn [B][9][cout][cin] in dtype. */
+int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, void* wdyn,
+                        void* stream);
+
+/* ---- 3x3 convolution, stride 1, zero pad 1 (F.conv2d at FDConv.py:699 / nn.Conv2d.forward) ---
+ * weights: [9][cout][cin] per sample; w_bstride = elements between samples (0: shared weights).
+ * With in->bands the A operand is FBM(x) = g1*x + (g2-g1)*L2 + (g3-g2)*L4 + (1-g3)*L8
+ * (FDConv.py:456-479) formed on the fly from `gates`.  out: (B,H,W,cout) view. */
+int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, const void* weights,
+               long w_bstride, int cout, const sr_epilogue* ep, sr_view out, void* stream);
+
+/* ---- whole network (RRDBNet.forward) ------------------------------------------------------- */
+typedef struct sr_rrdbnet sr_rrdbnet;
+int sr_rrdbnet_create(int num_in_ch, int num_out_ch, int scale, int num_feat, int num_block, int num_grow_ch,
+                      sr_rrdbnet** out);
+void sr_rrdbnet_destroy(sr_rrdbnet* net);
+int sr_rrdbnet_num_layers(const sr_rrdbnet* net);
+/* layer order = state_dict order: conv_first, body.i.rdbj.conv1..5, conv_body, conv_up1, conv_up2, conv_hr, conv_last */
+int sr_rrdbnet_set_layer(sr_rrdbnet* net, int index, const sr_layer_params* lp);
+/* builds the FBM plans for (H,W),(2H,2W),(4H,4W) of an input (B,C,Hin,Win); allocates tables */
+int sr_rrdbnet_prepare(sr_rrdbnet* net, int Hin, int Win);
+size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet* net, int dtype, int B, int Hin, int Win);
+/* x: NCHW (B,num_in_ch,Hin,Win) in io_dtype; y: NCHW (B,num_out_ch,Hin*scale... ) in io_dtype */
+int sr_rrdbnet_forward(sr_rrdbnet* net, int dtype, int io_dtype, int B, int Hin, int Win, const void* x, void* y,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* per-phase kernel-time attribution for bench.py: enables hipEvent timing around kernel groups
+ * on the next forward; read back (ms) after a stream sync.  groups: 0 conv 1 lowpass 2 gates
+ * 3 weightgen 4 layout */
+int sr_rrdbnet_profile(sr_rrdbnet* net, int enable);
+int sr_rrdbnet_profile_read(sr_rrdbnet* net, float* ms5, long* launches5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_AMD_H */

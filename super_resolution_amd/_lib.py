@@ -1,0 +1,135 @@
+"""ctypes binding of libsr_amd.so (include/sr_amd.h).
+
+The library is built in-tree by `super_resolution_amd/build.py` (hipcc, gfx950).  There is no
+fallback: if it is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsr_amd.so')
+
+SR_F32, SR_BF16 = 0, 1
+SR_MAX_SEG = 8
+
+
+class View(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('ld', C.c_int32), ('c0', C.c_int32), ('C', C.c_int32), ('_pad', C.c_int32)]
+
+
+class Concat(C.Structure):
+    _fields_ = [('nseg', C.c_int32), ('bands', C.c_int32), ('ups', C.c_int32), ('_pad', C.c_int32),
+                ('x', View * SR_MAX_SEG), ('l2', View * SR_MAX_SEG), ('l4', View * SR_MAX_SEG), ('l8', View * SR_MAX_SEG)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('lrelu', C.c_int32), ('_pad', C.c_int32),
+                ('r1', View), ('s1', C.c_float), ('_pad1', C.c_float),
+                ('r2', View), ('s2', C.c_float), ('_pad2', C.c_float)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [('cin', C.c_int32), ('cout', C.c_int32), ('active', C.c_int32), ('loc_taps', C.c_int32),
+                ('bias', C.c_void_p), ('wpacked', C.c_void_p), ('basis', C.c_void_p), ('fc_w', C.c_void_p),
+                ('bn_w', C.c_void_p), ('bn_b', C.c_void_p), ('bn_rm', C.c_void_p), ('bn_rv', C.c_void_p),
+                ('relu_s', C.c_void_p), ('relu_b', C.c_void_p),
+                ('ch_w', C.c_void_p), ('ch_b', C.c_void_p), ('fl_w', C.c_void_p), ('fl_b', C.c_void_p),
+                ('sp_w', C.c_void_p), ('sp_b', C.c_void_p), ('kn_w', C.c_void_p), ('kn_b', C.c_void_p),
+                ('gate_w', C.c_void_p * 3), ('gate_b', C.c_void_p * 3),
+                ('loc_w', C.c_void_p), ('ln_w', C.c_void_p), ('ln_b', C.c_void_p)]
+
+
+_SIGS = {
+    'sr_strerror': (C.c_char_p, [C.c_int]),
+    'sr_last_hip_error': (C.c_int, []),
+    'sr_version': (C.c_int, []),
+    'sr_pack_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_unpack_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_pack_conv_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_fbm_plan_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'sr_fbm_plan_destroy': (None, [C.c_void_p]),
+    'sr_fbm_masks_host': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'sr_fbm_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'sr_fbm_lowpass': (C.c_int, [C.c_void_p, C.c_int, C.c_int, View, C.c_int, View, View, View, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_fbm_gates': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.POINTER(LayerParams), C.c_void_p,
+                               C.c_void_p]),
+    'sr_fdconv_basis_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'sr_fdconv_basis': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_void_p]),
+    'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_void_p, C.c_void_p]),
+    'sr_conv3x3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, C.c_void_p, C.c_long,
+                             C.c_int, C.POINTER(Epilogue), View, C.c_void_p]),
+    'sr_rrdbnet_create': (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
+    'sr_rrdbnet_destroy': (None, [C.c_void_p]),
+    'sr_rrdbnet_num_layers': (C.c_int, [C.c_void_p]),
+    'sr_rrdbnet_set_layer': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(LayerParams)]),
+    'sr_rrdbnet_prepare': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    'sr_rrdbnet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'sr_rrdbnet_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_rrdbnet_profile': (C.c_int, [C.c_void_p, C.c_int]),
+    'sr_rrdbnet_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]),
+    'sr_debug_force_generic_conv': (None, [C.c_int]),
+}
+
+# every symbol include/sr_amd.h declares (the debug hook is not part of the header)
+HEADER_SYMBOLS = [n for n in _SIGS if n != 'sr_debug_force_generic_conv']
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('%s is missing: build it with `python -m super_resolution_amd.build` '
+                               '(hipcc --offload-arch=gfx950); there is no fallback path' % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(h, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().sr_strerror(rc).decode()
+        raise RuntimeError('libsr_amd %s failed: %s (code %d, hip error %d)' % (what, msg, rc, lib().sr_last_hip_error()))
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return SR_F32
+    if dt == torch.bfloat16:
+        return SR_BF16
+    raise TypeError('libsr_amd computes in float32 or bfloat16, got %s' % dt)
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def view(t, C_=None, c0=0):
+    """sr_view over the last (channel) axis of a contiguous NHWC tensor."""
+    ld = t.shape[-1]
+    return View(t.data_ptr(), ld, c0, ld - c0 if C_ is None else C_, 0)
+
+
+def null_view():
+    return View(None, 0, 0, 0, 0)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_gpu(t, who):
+    if not t.is_cuda:
+        raise RuntimeError('%s runs on an MI355X through libsr_amd only; got a %s tensor (no CPU path exists)'
+                           % (who, t.device))

@@ -1,0 +1,98 @@
+// Shared device/host helpers for libsr_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sr_amd.h"
+
+namespace sr {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return SR_ERR_HIP;
+}
+#define SR_HIP(call)                                   \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) return sr::hip_fail(_e); \
+    } while (0)
+#define SR_LAUNCH_CHECK() SR_HIP(hipGetLastError())
+#define SR_REQUIRE(cond)            \
+    do {                            \
+        if (!(cond)) return SR_ERR_ARG; \
+    } while (0)
+
+typedef uint16_t bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+inline size_t dtype_size(int dtype) { return dtype == SR_F32 ? 4 : 2; }
+inline bool dtype_ok(int dtype) { return dtype == SR_F32 || dtype == SR_BF16; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// device-side mirrors of the ABI structs (plain data, passed by value as kernel arguments)
+struct View {
+    char* p;
+    int ld, c0, C;
+};
+inline View to_view(const sr_view& v) { return View{(char*)v.p, v.ld, v.c0, v.C}; }
+
+struct Concat {
+    int nseg, bands, ups, ctot;
+    View x[SR_MAX_SEG], l2[SR_MAX_SEG], l4[SR_MAX_SEG], l8[SR_MAX_SEG];
+    int cstart[SR_MAX_SEG + 1];  // first concat channel of each segment
+};
+int to_concat(const sr_concat* in, Concat* out);  // validates; returns SR_OK / SR_ERR_ARG
+
+struct Epilogue {
+    const float* bias;
+    int lrelu;
+    View r1, r2;
+    float s1, s2;
+};
+inline Epilogue to_epilogue(const sr_epilogue* e) {
+    Epilogue o{};
+    if (e) {
+        o.bias = e->bias;
+        o.lrelu = e->lrelu;
+        o.r1 = to_view(e->r1);
+        o.r2 = to_view(e->r2);
+        o.s1 = e->s1;
+        o.s2 = e->s2;
+    }
+    return o;
+}
+
+// internal launchers shared with the network executor (same semantics as the extern "C" entry points)
+int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* weights,
+                   long w_bstride, int cout, const Epilogue& ep, View out, hipStream_t st);
+
+int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8,
+                       float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st);
+int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_layer_params& lp, float* gates,
+                     hipStream_t st);
+int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,
+                     hipStream_t st);
+
+}  // namespace sr

@@ -1,0 +1,360 @@
+// 3x3 convolution, stride 1, zero pad 1, NHWC, per-sample or shared weights, with
+//   * the dense-block concat as a list of input views (no torch.cat copy),
+//   * FBM modulation of the input formed in the loader (FDConv.py:456-479):
+//       a = g1*x + (g2-g1)*L2 + (g3-g2)*L4 + (1-g3)*L8,
+//   * nearest-2x upsampling folded into the loader (RRDBNet.forward),
+//   * bias / LeakyReLU(0.2) / two scaled residuals in the epilogue.
+//
+// Two kernels:
+//   conv3x3_mfma_bf16 : implicit GEMM on v_mfma_f32_32x32x16_bf16.  M = output channels (weights
+//                       are the A operand), N = 32 consecutive pixels of one image row, K = 9 taps x
+//                       32-channel chunks.  A workgroup (4 waves) owns a 16x32 pixel tile; the
+//                       haloed 18x34x32ch input tile and the 9 x Cout x 32ch weight slab sit in LDS
+//                       as 64-byte rows with a 16-byte-slot XOR swizzle so every ds_read_b128 of a
+//                       fragment is conflict-free.  Each lane ends up with 4 consecutive output
+//                       channels of one pixel per accumulator quad -> 8-byte NHWC stores.
+//   conv3x3_generic   : fp32-accumulate VALU kernel for any dtype / channel count (fp32 parity
+//                       path, 1- and 3-channel head and tail convs, odd-sized test networks).
+#include "common.h"
+
+namespace sr {
+
+// ---------------------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+template <typename T>
+__device__ __forceinline__ float epilogue_one(float acc, int o, long pix, const Epilogue& ep) {
+    float y = acc + (ep.bias ? ep.bias[o] : 0.f);
+    if (ep.lrelu) y = lrelu02(y);
+    if (ep.r1.p) y = y * ep.s1 + Elem<T>::ld((const T*)ep.r1.p + pix * ep.r1.ld + ep.r1.c0 + o);
+    if (ep.r2.p) y = y * ep.s2 + Elem<T>::ld((const T*)ep.r2.p + pix * ep.r2.ld + ep.r2.c0 + o);
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic VALU kernel
+// ---------------------------------------------------------------------------------------------
+constexpr int CT = 16;   // tile side
+constexpr int CCC = 8;   // channels per LDS stage
+
+template <typename T, int OT>
+__global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, const float* __restrict__ gates,
+                                                       const T* __restrict__ wts, long w_bstride, int cin, int cout,
+                                                       Epilogue ep, View out) {
+    __shared__ float tile[CCC][CT + 2][CT + 3];
+    __shared__ __attribute__((aligned(16))) float wsh[9][CCC][OT];
+    const int tilesx = (W + CT - 1) / CT;
+    const int b = blockIdx.y;
+    const int o0 = blockIdx.z * OT;
+    const int ty0 = (blockIdx.x / tilesx) * CT, tx0 = (blockIdx.x % tilesx) * CT;
+    const int ty = threadIdx.x / CT, tx = threadIdx.x % CT;
+    const int Hs = H >> in.ups, Ws = W >> in.ups;
+    const T* wb = wts + (long)b * w_bstride;
+    float acc[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) acc[o] = 0.f;
+    for (int s = 0; s < in.nseg; ++s) {
+        const View vx = in.x[s];
+        const T* bx = (const T*)vx.p + (long)b * Hs * Ws * vx.ld + vx.c0;
+        const T *b2 = nullptr, *b4 = nullptr, *b8 = nullptr;
+        if (in.bands) {
+            b2 = (const T*)in.l2[s].p + (long)b * H * W * in.l2[s].ld + in.l2[s].c0;
+            b4 = (const T*)in.l4[s].p + (long)b * H * W * in.l4[s].ld + in.l4[s].c0;
+            b8 = (const T*)in.l8[s].p + (long)b * H * W * in.l8[s].ld + in.l8[s].c0;
+        }
+        for (int cc = 0; cc < vx.C; cc += CCC) {
+            const int nc = min(CCC, vx.C - cc);
+            __syncthreads();
+            for (int it = threadIdx.x; it < (CT + 2) * (CT + 2) * nc; it += blockDim.x) {
+                const int c = it % nc, pi = it / nc;
+                const int py = pi / (CT + 2), px = pi % (CT + 2);
+                const int h = ty0 + py - 1, w = tx0 + px - 1;
+                float val = 0.f;
+                if (h >= 0 && h < H && w >= 0 && w < W) {
+                    val = Elem<T>::ld(bx + ((long)(h >> in.ups) * Ws + (w >> in.ups)) * vx.ld + cc + c);
+                    if (in.bands) {
+                        const long p = (long)h * W + w;
+                        const float4 g = ((const float4*)gates)[(long)b * H * W + p];
+                        const float v2 = Elem<T>::ld(b2 + p * in.l2[s].ld + cc + c);
+                        const float v4 = Elem<T>::ld(b4 + p * in.l4[s].ld + cc + c);
+                        const float v8 = Elem<T>::ld(b8 + p * in.l8[s].ld + cc + c);
+                        val = g.x * val + (g.y - g.x) * v2 + (g.z - g.y) * v4 + (1.0f - g.z) * v8;
+                    }
+                }
+                tile[c][py][px] = val;
+            }
+            for (int it = threadIdx.x; it < 9 * nc * OT; it += blockDim.x) {
+                const int o = it % OT, c = (it / OT) % nc, tap = it / (OT * nc);
+                float wv = 0.f;
+                if (o0 + o < cout) wv = Elem<T>::ld(wb + ((long)tap * cout + o0 + o) * cin + in.cstart[s] + cc + c);
+                wsh[tap][c][o] = wv;
+            }
+            __syncthreads();
+            for (int c = 0; c < nc; ++c) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float x = tile[c][ty + tap / 3][tx + tap % 3];
+#pragma unroll
+                    for (int o = 0; o < OT; ++o) acc[o] += x * wsh[tap][c][o];
+                }
+            }
+        }
+    }
+    const int h = ty0 + ty, w = tx0 + tx;
+    if (h < H && w < W) {
+        const long pix = ((long)b * H + h) * W + w;
+        T* po = (T*)out.p + pix * out.ld + out.c0;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+            if (o0 + o < cout) Elem<T>::st(po + o0 + o, epilogue_one<T>(acc[o], o0 + o, pix, ep));
+    }
+}
+
+template <typename T>
+static int launch_generic(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
+                          int cout, const Epilogue& ep, View out, hipStream_t st) {
+    const int tiles = cdiv(H, CT) * cdiv(W, CT);
+#define SR_GEN(OT)                                                                                                   \
+    conv3x3_generic<T, OT><<<dim3(tiles, B, cdiv(cout, OT)), 256, 0, st>>>(in, H, W, gates, (const T*)wts, wbs, in.ctot, \
+                                                                          cout, ep, out)
+    if (cout <= 4) SR_GEN(4);
+    else if (cout <= 8) SR_GEN(8);
+    else if (cout <= 16) SR_GEN(16);
+    else SR_GEN(32);
+#undef SR_GEN
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short short8;
+typedef __attribute__((ext_vector_type(16))) float float16v;
+
+constexpr int MTH = 16, MTW = 32;            // pixel tile
+constexpr int PH = MTH + 2, PW = MTW + 2;    // haloed tile
+constexpr int NPIX = PH * PW;                // 612 rows of 64 B
+
+// byte offset of 16-byte slot `chunk` (0..3) of 64-byte row `row`, XOR-swizzled so that the 16
+// lanes of every ds_read_b128 lane group (rows distinct mod 16) land on 16 distinct slots.
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, float c0, float c1, float c2, float c3) {
+    uint4 r;
+    r.x = pack2(c0 * lo_f(x.x) + c1 * lo_f(a.x) + c2 * lo_f(b.x) + c3 * lo_f(c.x),
+                c0 * hi_f(x.x) + c1 * hi_f(a.x) + c2 * hi_f(b.x) + c3 * hi_f(c.x));
+    r.y = pack2(c0 * lo_f(x.y) + c1 * lo_f(a.y) + c2 * lo_f(b.y) + c3 * lo_f(c.y),
+                c0 * hi_f(x.y) + c1 * hi_f(a.y) + c2 * hi_f(b.y) + c3 * hi_f(c.y));
+    r.z = pack2(c0 * lo_f(x.z) + c1 * lo_f(a.z) + c2 * lo_f(b.z) + c3 * lo_f(c.z),
+                c0 * hi_f(x.z) + c1 * hi_f(a.z) + c2 * hi_f(b.z) + c3 * hi_f(c.z));
+    r.w = pack2(c0 * lo_f(x.w) + c1 * lo_f(a.w) + c2 * lo_f(b.w) + c3 * lo_f(c.w),
+                c0 * hi_f(x.w) + c1 * hi_f(a.w) + c2 * hi_f(b.w) + c3 * hi_f(c.w));
+    return r;
+}
+
+// MT = number of 32-wide output-channel tiles handled by the workgroup (1 or 2)
+template <int MT, bool BANDS>
+__global__ __launch_bounds__(256) void conv3x3_mfma_bf16(Concat in, int H, int W, const float* __restrict__ gates,
+                                                         const bf16_t* __restrict__ wts, long w_bstride, int cin,
+                                                         int cout, Epilogue ep, View out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* lds_px = lds;                 // NPIX rows x 64 B
+    char* lds_w = lds + NPIX * 64;      // 9*MT*32 rows x 64 B
+    const int tilesx = (W + MTW - 1) / MTW;
+    const int b = blockIdx.y;
+    const int o_blk = blockIdx.z * (MT * 32);
+    const int h0 = (blockIdx.x / tilesx) * MTH, w0 = (blockIdx.x % tilesx) * MTW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hk = lane >> 5;
+    const int Hs = H >> in.ups, Ws = W >> in.ups;
+    const bf16_t* wb = wts + (long)b * w_bstride;
+
+    float16v acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    int kc = 0;  // first concat channel of the current 32-channel chunk
+    for (int s = 0; s < in.nseg; ++s) {
+        const View vx = in.x[s];
+        for (int cc = 0; cc < vx.C; cc += 32, kc += 32) {
+            __syncthreads();
+            // ---- stage the haloed pixel tile: 612 pixels x 4 slots of 8 channels -------------------
+            for (int it = tid; it < NPIX * 4; it += 256) {
+                const int chunk = it & 3, pi = it >> 2;
+                const int py = pi / PW, px = pi - py * PW;
+                const int h = h0 + py - 1, w = w0 + px - 1;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (h >= 0 && h < H && w >= 0 && w < W) {
+                    const long ps = ((long)b * Hs + (h >> in.ups)) * Ws + (w >> in.ups);
+                    v = *(const uint4*)((const bf16_t*)vx.p + ps * vx.ld + vx.c0 + cc + chunk * 8);
+                    if (BANDS) {
+                        const long p = ((long)b * H + h) * W + w;
+                        const float4 g = ((const float4*)gates)[p];
+                        const uint4 a2 = *(const uint4*)((const bf16_t*)in.l2[s].p + p * in.l2[s].ld + in.l2[s].c0 + cc + chunk * 8);
+                        const uint4 a4 = *(const uint4*)((const bf16_t*)in.l4[s].p + p * in.l4[s].ld + in.l4[s].c0 + cc + chunk * 8);
+                        const uint4 a8 = *(const uint4*)((const bf16_t*)in.l8[s].p + p * in.l8[s].ld + in.l8[s].c0 + cc + chunk * 8);
+                        v = modulate8(v, a2, a4, a8, g.x, g.y - g.x, g.z - g.y, 1.0f - g.z);
+                    }
+                }
+                *(uint4*)(lds_px + swz(pi, chunk)) = v;
+            }
+            // ---- stage the weight slab: rows (tap, o) x 32 channels ---------------------------------
+            for (int it = tid; it < 9 * MT * 32 * 4; it += 256) {
+                const int chunk = it & 3, row = it >> 2;
+                const int tap = row / (MT * 32), o = row - tap * (MT * 32);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (o_blk + o < cout) v = *(const uint4*)(wb + ((long)tap * cout + o_blk + o) * cin + kc + chunk * 8);
+                *(uint4*)(lds_w + swz(row, chunk)) = v;
+            }
+            __syncthreads();
+            // ---- 9 taps x 2 k-steps of 16 channels --------------------------------------------------
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int chunk = kk * 2 + hk;
+                    short8 af[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[m] = *(const short8*)(lds_w + swz(tap * (MT * 32) + m * 32 + r, chunk));
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int pi = (wave * 4 + n + dy) * PW + r + dx;
+                        const short8 bf = *(const short8*)(lds_px + swz(pi, chunk));
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: lane holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each tile ----
+    const int w = w0 + r;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int h = h0 + wave * 4 + n;
+        if (h >= H || w >= W) continue;
+        const long pix = ((long)b * H + h) * W + w;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = o_blk + m * 32 + q * 8 + hk * 4;
+                if (o >= cout) continue;
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = acc[m][n][q * 4 + j] + (ep.bias ? ep.bias[o + j] : 0.f);
+                if (ep.lrelu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = lrelu02(y[j]);
+                }
+                if (ep.r1.p) {
+                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r1.p + pix * ep.r1.ld + ep.r1.c0 + o);
+                    y[0] = y[0] * ep.s1 + lo_f(rr.x);
+                    y[1] = y[1] * ep.s1 + hi_f(rr.x);
+                    y[2] = y[2] * ep.s1 + lo_f(rr.y);
+                    y[3] = y[3] * ep.s1 + hi_f(rr.y);
+                }
+                if (ep.r2.p) {
+                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r2.p + pix * ep.r2.ld + ep.r2.c0 + o);
+                    y[0] = y[0] * ep.s2 + lo_f(rr.x);
+                    y[1] = y[1] * ep.s2 + hi_f(rr.x);
+                    y[2] = y[2] * ep.s2 + lo_f(rr.y);
+                    y[3] = y[3] * ep.s2 + hi_f(rr.y);
+                }
+                uint2 st;
+                st.x = pack2(y[0], y[1]);
+                st.y = pack2(y[2], y[3]);
+                *(uint2*)((bf16_t*)out.p + pix * out.ld + out.c0 + o) = st;
+            }
+        }
+    }
+}
+
+static bool view_vec_ok(const View& v, int mult) {
+    return v.p && ((uintptr_t)v.p % 16 == 0) && v.ld % mult == 0 && v.c0 % mult == 0;
+}
+
+static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const View& out, const void* wts,
+                          long wbs) {
+    if (cout % 32 != 0) return false;
+    if ((uintptr_t)wts % 16 != 0 || wbs % 8 != 0) return false;
+    for (int s = 0; s < in.nseg; ++s) {
+        if (in.x[s].C % 32 != 0 || !view_vec_ok(in.x[s], 8)) return false;
+        if (in.bands && (!view_vec_ok(in.l2[s], 8) || !view_vec_ok(in.l4[s], 8) || !view_vec_ok(in.l8[s], 8)))
+            return false;
+    }
+    if (!view_vec_ok(out, 4)) return false;
+    if (ep.r1.p && !view_vec_ok(ep.r1, 4)) return false;
+    if (ep.r2.p && !view_vec_ok(ep.r2, 4)) return false;
+    return true;
+}
+
+template <int MT, bool BANDS>
+static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, int cout,
+                       const Epilogue& ep, View out, hipStream_t st) {
+    const size_t ldsb = (size_t)NPIX * 64 + 9ul * MT * 32 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_bf16<MT, BANDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)ldsb));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(H, MTH) * cdiv(W, MTW), B, cdiv(cout, MT * 32));
+    conv3x3_mfma_bf16<MT, BANDS><<<grid, 256, ldsb, st>>>(in, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
+
+int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
+                   int cout, const Epilogue& ep, View out, hipStream_t st) {
+    if (dtype == SR_F32) return launch_generic<float>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+    if (!g_force_generic && mfma_eligible(in, cout, ep, out, wts, wbs)) {
+        const bool two = (cout % 64 == 0);
+        if (in.bands)
+            return two ? launch_mfma<2, true>(B, H, W, in, gates, wts, wbs, cout, ep, out, st)
+                       : launch_mfma<1, true>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+        return two ? launch_mfma<2, false>(B, H, W, in, gates, wts, wbs, cout, ep, out, st)
+                   : launch_mfma<1, false>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+    }
+    return launch_generic<bf16_t>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+}
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, const void* weights,
+                          long w_bstride, int cout, const sr_epilogue* ep, sr_view out, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && in && weights && cout > 0 && out.p);
+    SR_REQUIRE(B <= 65535 && w_bstride >= 0);
+    Concat c;
+    int rc = to_concat(in, &c);
+    if (rc != SR_OK) return rc;
+    SR_REQUIRE(!c.bands || gates);
+    SR_REQUIRE(!c.ups || (H % 2 == 0 && W % 2 == 0));
+    SR_REQUIRE(out.C == cout && out.c0 >= 0 && out.c0 + cout <= out.ld);
+    Epilogue e = to_epilogue(ep);
+    SR_REQUIRE(!e.r1.p || (e.r1.C == cout && e.r1.c0 + cout <= e.r1.ld));
+    SR_REQUIRE(!e.r2.p || (e.r2.C == cout && e.r2.c0 + cout <= e.r2.ld));
+    return conv3x3_launch(dtype, B, H, W, c, gates, weights, w_bstride, cout, e, to_view(out), (hipStream_t)stream);
+}
+
+// test hook (not part of the product API): 1 routes bf16 convs through the VALU kernel
+extern "C" void sr_debug_force_generic_conv(int on) { sr::g_force_generic = on; }

@@ -1,0 +1,433 @@
+// FBM low-pass planes: L_k = irfft2(rfft2(x) * mask_k), k = 2,4,8  (FDConv.py:427-457).
+//
+// MI355X formulation.  Activations are NHWC, so the channel axis is the SIMD axis: two real
+// channels are packed into one complex signal z = x_a + i*x_b and a plain complex 2-D FFT is
+// run with consecutive lanes on consecutive channel pairs (conflict-free LDS, wave-uniform
+// twiddles).  Because the box masks are real and applied identically to both channels,
+//     L_a + i*L_b = ifft2( fft2(z) * Mfull_k )
+// where Mfull_k is the full-plane mask equivalent to the reference's half-spectrum mask plus
+// C2R semantics (oracle/fdconv_ref.py: fbm_full_masks).  Three kernels, all in fp32:
+//   rows_fwd : FFT along W of every image row, keeps only the columns mask k=2 keeps
+//   cols     : FFT along H of every kept column, then per mask: row mask, inverse FFT along H
+//   rows_inv : per mask: scatter kept columns, inverse FFT along W, real/imag -> channel pair
+// The DC bin of the column pass is the plane sum, so adaptive_avg_pool2d (FDConv.py:643) is a
+// by-product.  The FFT is a Stockham autosort with a runtime radix list (any length whose
+// factors are small), one output per work item per pass.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+struct sr_fbm_plan {
+    int H, W;
+    int nfW, nfH;
+    int radW[24], radH[24];
+    int Pw, Ph;            // channel pairs per workgroup in the row / column passes
+    int n[3];              // kept full-spectrum columns for k=2,4,8
+    float2* tw_w;          // device: exp(-2*pi*i*j/W)
+    float2* tw_h;          // device: exp(-2*pi*i*j/H)
+    int* cols;             // device: [n[0]] kept column index (mask k=2), ascending
+    int* colinfo;          // device: [n[0]][4] = {variant, index in k=4 list or -1, index in k=8 list or -1, 0}
+    int* cols4;            // device: [n[1]]
+    int* cols8;            // device: [n[2]]
+    float* rowmask;        // device: [3 masks][3 variants][H]
+    void* dev_block;       // one allocation backing all of the above
+};
+
+namespace sr {
+
+// ---- host: masks --------------------------------------------------------------------------
+static void base_masks(bool rows[3][64], bool cols[3][33]) {
+    // FDConv.py:393-415 evaluated in float32: k=2 strict (|f| < 0.25), k=4,8 inclusive.
+    const int K[3] = {2, 4, 8};
+    for (int k = 0; k < 3; ++k) {
+        const float thr = (float)(0.5 / K[k] + 1e-8);
+        for (int r = 0; r < 64; ++r) {
+            const int s = r < 32 ? r : r - 64;  // fftfreq(64): 0..31, -32..-1
+            rows[k][r] = fabsf((float)s / 64.0f) < thr;
+        }
+        for (int c = 0; c < 33; ++c) cols[k][c] = ((float)c / 64.0f) < thr;
+    }
+}
+
+static int nearest_src(int dst, int in, int out) {
+    // ATen legacy 'nearest': scale = (float)in / out; src = min((int)floorf(dst * scale), in - 1)
+    if (out == in) return dst;
+    if (out == 2 * in) return dst >> 1;
+    const float scale = (float)in / (float)out;
+    int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+static void resized_masks(int H, int W, uint8_t* rows /*3*H*/, uint8_t* cols /*3*(W/2+1)*/) {
+    bool r64[3][64], c33[3][33];
+    base_masks(r64, c33);
+    const int wh = W / 2 + 1;
+    for (int k = 0; k < 3; ++k) {
+        for (int r = 0; r < H; ++r) rows[k * H + r] = r64[k][nearest_src(r, 64, H)];
+        for (int c = 0; c < wh; ++c) cols[k * wh + c] = c33[k][nearest_src(c, 33, wh)];
+    }
+}
+
+static int factorize(int n, int* rad) {
+    int nf = 0;
+    while (n % 4 == 0) { rad[nf++] = 4; n /= 4; }
+    for (int p = 2; p * p <= n; ++p)
+        while (n % p == 0) { rad[nf++] = p; n /= p; }
+    if (n > 1) rad[nf++] = n;
+    return nf;
+}
+
+static int pairs_per_group(int n) {
+    int p = 16;
+    while (p > 1 && (long)n * p > 4096) p >>= 1;
+    return p;
+}
+
+// ---- device: Stockham pass -----------------------------------------------------------------
+struct Radix {
+    int nf;
+    int r[24];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One autosort pass of radix R over `src` (N points x P signals, signal index innermost).
+// Each work item produces one output point of one signal.  `premul`, when set, scales source
+// point i by premul[i] (the row mask, applied while reading the spectrum).
+template <bool INV>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
+                                         int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+    const int NR = N / R;
+    const int tstep = N / (Ns * R);
+    for (int it = threadIdx.x; it < N * P; it += blockDim.x) {
+        const int p = it % P;
+        const int o = it / P;
+        const int k = o % Ns;
+        const int u = (o / Ns) % R;
+        const int j = (o / (Ns * R)) * Ns + k;
+        const int q = k * tstep + u * NR;  // < N
+        float2 acc = make_float2(0.f, 0.f);
+        int tq = 0;
+        for (int t = 0; t < R; ++t) {
+            float2 w = tw[tq];
+            if (INV) w.y = -w.y;
+            const int si = j + t * NR;
+            float2 v = src[si * P + p];
+            if (premul) {
+                const float m = premul[si];
+                v.x *= m;
+                v.y *= m;
+            }
+            acc.x += v.x * w.x - v.y * w.y;
+            acc.y += v.x * w.y + v.y * w.x;
+            tq += q;
+            if (tq >= N) tq -= N;
+        }
+        dst[o * P + p] = acc;
+    }
+}
+
+// Runs all passes; returns the buffer that holds the result.  bufA holds the input.  When
+// `keep_input` is set the input buffer is never written (needs a third buffer bufC).
+template <bool INV>
+__device__ float2* fft_run(float2* bufA, float2* bufB, float2* bufC, bool keep_input, int N, const Radix& rx, int P,
+                           const float2* tw, const float* premul) {
+    float2* src = bufA;
+    float2* dst = bufB;
+    int Ns = 1;
+    for (int f = 0; f < rx.nf; ++f) {
+        fft_pass<INV>(src, dst, N, rx.r[f], Ns, P, tw, f == 0 ? premul : nullptr);
+        __syncthreads();
+        Ns *= rx.r[f];
+        float2* nxt = (src == bufA && keep_input) ? bufC : src;
+        src = dst;
+        dst = nxt;
+    }
+    return src;
+}
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+// ---- kernel 1: forward FFT along W ---------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int W, int C, int PT, int P, Radix rx,
+                                                    const float2* __restrict__ tw, const int* __restrict__ cols, int n2,
+                                                    float2* __restrict__ t1) {
+    float2* bufA = (float2*)smem;
+    float2* bufB = bufA + W * P;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int p0 = blockIdx.y * P;
+    const int Hs = H >> ups, Ws = W >> ups;
+    const T* row = (const T*)x.p + ((long)b * Hs + (h >> ups)) * Ws * x.ld + x.c0;
+    for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
+        const int p = it % P, w = it / P;
+        const int c = 2 * (p0 + p);
+        const T* px = row + (long)(w >> ups) * x.ld + c;
+        float2 v = make_float2(0.f, 0.f);
+        if (c < C) v.x = Elem<T>::ld(px);
+        if (c + 1 < C) v.y = Elem<T>::ld(px + 1);
+        bufA[it] = v;
+    }
+    __syncthreads();
+    const float2* res = fft_run<false>(bufA, bufB, nullptr, false, W, rx, P, tw, nullptr);
+    // t1[b][idx][h][PT]
+    for (int it = threadIdx.x; it < n2 * P; it += blockDim.x) {
+        const int p = it % P, idx = it / P;
+        if (p0 + p < PT) t1[(((long)b * n2 + idx) * H + h) * PT + p0 + p] = res[cols[idx] * P + p];
+    }
+}
+
+// ---- kernel 2: FFT along H, row masks, inverse FFT along H ----------------------------------
+__global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Radix rx, const float2* __restrict__ tw,
+                                                const int* __restrict__ colinfo, int n2, int n4, int n8,
+                                                const float* __restrict__ rowmask, const float2* __restrict__ t1,
+                                                float2* __restrict__ y2, float2* __restrict__ y4,
+                                                float2* __restrict__ y8, float* __restrict__ pooled, int pooled_ld,
+                                                int C) {
+    float2* buf0 = (float2*)smem;
+    float2* buf1 = buf0 + H * P;
+    float2* buf2 = buf1 + H * P;
+    const int b = blockIdx.x / n2, idx = blockIdx.x % n2;
+    const int p0 = blockIdx.y * P;
+    const float2* col = t1 + ((long)b * n2 + idx) * H * PT;
+    for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
+        const int p = it % P, h = it / P;
+        buf0[it] = (p0 + p < PT) ? col[(long)h * PT + p0 + p] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    float2* S = fft_run<false>(buf0, buf1, nullptr, false, H, rx, P, tw, nullptr);
+    float2* other = (S == buf0) ? buf1 : buf0;
+    const int variant = colinfo[idx * 4 + 0];
+    if (pooled && idx == 0 && threadIdx.x < P) {  // column 0 comes first: S[0] = plane sums of the pair
+        const int c = 2 * (p0 + threadIdx.x);
+        const float inv = 1.0f / ((float)H * (float)W);
+        if (c < C) pooled[(long)b * pooled_ld + c] = S[threadIdx.x].x * inv;
+        if (c + 1 < C) pooled[(long)b * pooled_ld + c + 1] = S[threadIdx.x].y * inv;
+    }
+    const int kidx[3] = {idx, colinfo[idx * 4 + 1], colinfo[idx * 4 + 2]};
+    const int nk[3] = {n2, n4, n8};
+    float2* ys[3] = {y2, y4, y8};
+    for (int k = 0; k < 3; ++k) {
+        if (kidx[k] < 0) continue;  // block-uniform
+        const float* rm = rowmask + (k * 3 + variant) * H;
+        const float2* res = fft_run<true>(S, buf2, other, true, H, rx, P, tw, rm);
+        float2* y = ys[k];
+        for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
+            const int p = it % P, h = it / P;
+            if (p0 + p < PT) y[(((long)b * H + h) * nk[k] + kidx[k]) * PT + p0 + p] = res[it];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- kernel 3: inverse FFT along W, write the three low-pass tensors ------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, int H, int W, int C, int PT, int P,
+                                                    Radix rx, const float2* __restrict__ tw,
+                                                    const int* __restrict__ cols2, const int* __restrict__ cols4,
+                                                    const int* __restrict__ cols8, int n2, int n4, int n8,
+                                                    const float2* __restrict__ y2, const float2* __restrict__ y4,
+                                                    const float2* __restrict__ y8) {
+    float2* bufA = (float2*)smem;
+    float2* bufB = bufA + W * P;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int p0 = blockIdx.y * P;
+    const float norm = 1.0f / ((float)H * (float)W);
+    const int nk[3] = {n2, n4, n8};
+    const int* ck[3] = {cols2, cols4, cols8};
+    const float2* ys[3] = {y2, y4, y8};
+    const View outs[3] = {l2, l4, l8};
+    for (int k = 0; k < 3; ++k) {
+        for (int it = threadIdx.x; it < W * P; it += blockDim.x) bufA[it] = make_float2(0.f, 0.f);
+        __syncthreads();
+        const float2* yr = ys[k] + ((long)b * H + h) * nk[k] * PT;
+        for (int it = threadIdx.x; it < nk[k] * P; it += blockDim.x) {
+            const int p = it % P, i = it / P;
+            if (p0 + p < PT) bufA[ck[k][i] * P + p] = yr[(long)i * PT + p0 + p];
+        }
+        __syncthreads();
+        const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, tw, nullptr);
+        T* row = (T*)outs[k].p + ((long)b * H + h) * W * outs[k].ld + outs[k].c0;
+        for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
+            const int p = it % P, w = it / P;
+            const int c = 2 * (p0 + p);
+            const float2 v = res[it];
+            T* px = row + (long)w * outs[k].ld + c;
+            if (c < C) Elem<T>::st(px, v.x * norm);
+            if (c + 1 < C) Elem<T>::st(px + 1, v.y * norm);
+        }
+        __syncthreads();
+    }
+}
+
+static Radix make_radix(const int* r, int nf) {
+    Radix x{};
+    x.nf = nf;
+    for (int i = 0; i < nf; ++i) x.r[i] = r[i];
+    return x;
+}
+
+int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8,
+                       float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int H = pl->H, W = pl->W, C = x.C;
+    const int PT = (C + 1) / 2;
+    if (ws_bytes < sr_fbm_workspace_bytes(pl, B, C)) return SR_ERR_WORKSPACE;
+    const int n2 = pl->n[0], n4 = pl->n[1], n8 = pl->n[2];
+    float2* t1 = (float2*)ws;
+    float2* y2 = t1 + (size_t)B * n2 * H * PT;
+    float2* y4 = y2 + (size_t)B * H * n2 * PT;
+    float2* y8 = y4 + (size_t)B * H * n4 * PT;
+    const Radix rw = make_radix(pl->radW, pl->nfW), rh = make_radix(pl->radH, pl->nfH);
+    const int Pw = pl->Pw, Ph = pl->Ph;
+    const size_t lds_w = 2ul * W * Pw * sizeof(float2), lds_h = 3ul * H * Ph * sizeof(float2);
+    dim3 g1(B * H, cdiv(PT, Pw)), g2(B * n2, cdiv(PT, Ph));
+    if (dtype == SR_F32) {
+        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_inv<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+    } else {
+        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_fwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_inv<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+    }
+    SR_HIP(hipFuncSetAttribute((const void*)fbm_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+    if (dtype == SR_F32)
+        fbm_rows_fwd<float><<<g1, 256, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+    else
+        fbm_rows_fwd<bf16_t><<<g1, 256, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+    SR_LAUNCH_CHECK();
+    fbm_cols<<<g2, 256, lds_h, st>>>(H, W, PT, Ph, rh, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
+                                     pooled, pooled_ld, C);
+    SR_LAUNCH_CHECK();
+    if (dtype == SR_F32)
+        fbm_rows_inv<float><<<g1, 256, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+                                                    pl->cols8, n2, n4, n8, y2, y4, y8);
+    else
+        fbm_rows_inv<bf16_t><<<g1, 256, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+                                                     pl->cols8, n2, n4, n8, y2, y4, y8);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host) {
+    SR_REQUIRE(H > 0 && W > 0 && rows_host && cols_host);
+    resized_masks(H, W, rows_host, cols_host);
+    return SR_OK;
+}
+
+extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
+    SR_REQUIRE(out && H >= 1 && W >= 1 && H <= 4096 && W <= 4096);
+    sr_fbm_plan* pl = (sr_fbm_plan*)calloc(1, sizeof(sr_fbm_plan));
+    if (!pl) return SR_ERR_ARG;
+    pl->H = H;
+    pl->W = W;
+    pl->nfW = factorize(W, pl->radW);
+    pl->nfH = factorize(H, pl->radH);
+    pl->Pw = pairs_per_group(W);
+    pl->Ph = pairs_per_group(H);
+    const int wh = W / 2 + 1;
+    std::vector<uint8_t> rows(3 * H), cols(3 * wh);
+    resized_masks(H, W, rows.data(), cols.data());
+    // kept full-spectrum columns per mask, ascending; variant: 0 = rm[r], 1 = rm[-r], 2 = average
+    std::vector<int> lists[3];
+    for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < W; ++c) {
+            const int ch = c <= W / 2 ? c : W - c;
+            if (cols[k * wh + ch]) lists[k].push_back(c);
+        }
+    for (int k = 0; k < 3; ++k) pl->n[k] = (int)lists[k].size();
+    if (pl->n[0] < 1) { free(pl); return SR_ERR_ARG; }
+    std::vector<int> info(4 * lists[0].size());
+    for (size_t i = 0; i < lists[0].size(); ++i) {
+        const int c = lists[0][i];
+        int variant;
+        if (c == 0 || (W % 2 == 0 && c == W / 2)) variant = 2;
+        else variant = c < (W + 1) / 2 ? 0 : 1;
+        info[4 * i + 0] = variant;
+        for (int k = 1; k < 3; ++k) {
+            int pos = -1;
+            for (size_t j = 0; j < lists[k].size(); ++j)
+                if (lists[k][j] == c) pos = (int)j;
+            info[4 * i + k] = pos;
+        }
+        info[4 * i + 3] = 0;
+    }
+    for (int k = 1; k < 3; ++k)  // masks must be nested, or a k=4/8 column would never be computed
+        for (int c : lists[k]) {
+            bool found = false;
+            for (int c2 : lists[0]) found |= (c2 == c);
+            if (!found) { free(pl); return SR_ERR_ARG; }
+        }
+    std::vector<float> rmask(9 * H);
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < H; ++r) {
+            const float a = rows[k * H + r], bneg = rows[k * H + (H - r) % H];
+            rmask[(k * 3 + 0) * H + r] = a;
+            rmask[(k * 3 + 1) * H + r] = bneg;
+            rmask[(k * 3 + 2) * H + r] = 0.5f * (a + bneg);
+        }
+    std::vector<float2> tww(W), twh(H);
+    for (int j = 0; j < W; ++j) tww[j] = make_float2((float)cos(-2.0 * M_PI * j / W), (float)sin(-2.0 * M_PI * j / W));
+    for (int j = 0; j < H; ++j) twh[j] = make_float2((float)cos(-2.0 * M_PI * j / H), (float)sin(-2.0 * M_PI * j / H));
+    // one device allocation, 256-byte aligned carve
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_tww = carve(W * sizeof(float2)), o_twh = carve(H * sizeof(float2));
+    const size_t o_cols = carve(lists[0].size() * 4), o_info = carve(info.size() * 4);
+    const size_t o_c4 = carve((lists[1].size() + 1) * 4), o_c8 = carve((lists[2].size() + 1) * 4);
+    const size_t o_rm = carve(rmask.size() * 4);
+    char* dev = nullptr;
+    hipError_t e = hipMalloc((void**)&dev, off);
+    if (e != hipSuccess) { free(pl); return hip_fail(e); }
+    std::vector<char> host(off, 0);
+    memcpy(&host[o_tww], tww.data(), W * sizeof(float2));
+    memcpy(&host[o_twh], twh.data(), H * sizeof(float2));
+    memcpy(&host[o_cols], lists[0].data(), lists[0].size() * 4);
+    memcpy(&host[o_info], info.data(), info.size() * 4);
+    if (!lists[1].empty()) memcpy(&host[o_c4], lists[1].data(), lists[1].size() * 4);
+    if (!lists[2].empty()) memcpy(&host[o_c8], lists[2].data(), lists[2].size() * 4);
+    memcpy(&host[o_rm], rmask.data(), rmask.size() * 4);
+    e = hipMemcpy(dev, host.data(), off, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dev); free(pl); return hip_fail(e); }
+    pl->dev_block = dev;
+    pl->tw_w = (float2*)(dev + o_tww);
+    pl->tw_h = (float2*)(dev + o_twh);
+    pl->cols = (int*)(dev + o_cols);
+    pl->colinfo = (int*)(dev + o_info);
+    pl->cols4 = (int*)(dev + o_c4);
+    pl->cols8 = (int*)(dev + o_c8);
+    pl->rowmask = (float*)(dev + o_rm);
+    *out = pl;
+    return SR_OK;
+}
+
+extern "C" void sr_fbm_plan_destroy(sr_fbm_plan* pl) {
+    if (!pl) return;
+    if (pl->dev_block) (void)hipFree(pl->dev_block);
+    free(pl);
+}
+
+extern "C" size_t sr_fbm_workspace_bytes(const sr_fbm_plan* pl, int B, int C) {
+    if (!pl || B < 1 || C < 1) return 0;
+    const size_t PT = (C + 1) / 2;
+    const size_t n = (size_t)pl->n[0] * 2 + pl->n[1] + pl->n[2];
+    return align_up((size_t)B * pl->H * n * PT * sizeof(float2), 256);
+}
+
+extern "C" int sr_fbm_lowpass(const sr_fbm_plan* pl, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4,
+                              sr_view l8, float* pooled, int pooled_ld, void* ws, size_t ws_bytes, void* stream) {
+    SR_REQUIRE(pl && dtype_ok(dtype) && B > 0 && x.p && l2.p && l4.p && l8.p && ws);
+    SR_REQUIRE(x.C > 0 && l2.C == x.C && l4.C == x.C && l8.C == x.C);
+    SR_REQUIRE(x.c0 >= 0 && x.c0 + x.C <= x.ld && l2.c0 + x.C <= l2.ld && l4.c0 + x.C <= l4.ld && l8.c0 + x.C <= l8.ld);
+    SR_REQUIRE(ups == 0 || (pl->H % 2 == 0 && pl->W % 2 == 0));
+    SR_REQUIRE(!pooled || pooled_ld >= x.C);
+    return fbm_lowpass_launch(pl, dtype, B, to_view(x), ups ? 1 : 0, to_view(l2), to_view(l4), to_view(l8), pooled,
+                              pooled_ld, ws, ws_bytes, (hipStream_t)stream);
+}

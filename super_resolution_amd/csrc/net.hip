@@ -1,0 +1,448 @@
+// RRDBNet executor: one C call enqueues the whole generator (RRDBNet.forward of basicsr 1.4.2 as
+// called at train/train_realESRGAN_fdconv_1.py:114 and realesrgan/utils.py:115,160) on a stream.
+//
+// Memory plan (all inside the caller's workspace, NHWC in the compute dtype):
+//   * every produced tensor is its own dense array; the dense-block concat is the list of views the
+//     conv kernel walks, never a copy;
+//   * each tensor that feeds an FDConv layer gets its three FBM low-pass tensors and its pooled
+//     means exactly once (shared by every later conv of the dense block that reads it);
+//   * the trunk ping-pongs between three 64-channel buffers so that the RDB input, the RRDB input and
+//     the output never alias; the two nearest-2x upsamples are folded into the loaders.
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+using namespace sr;
+
+namespace {
+struct Tensor {
+    View x{};
+    View band[3]{};
+    int C = 0;
+    int res = 0;        // 0: HxW, 1: 2Hx2W, 2: 4Hx4W  (resolution of the tensor itself)
+    bool bands_ready = false;
+    int bands_ups = 0;  // bands were computed for the 2x-upsampled tensor
+};
+
+struct ProfEvent {
+    int group;
+    hipEvent_t a, b;
+};
+}  // namespace
+
+struct sr_rrdbnet {
+    int in_ch, out_ch, scale, nf, nb, gc;
+    int r, cin0;
+    std::vector<sr_layer_params> layers;
+    std::vector<char> is_set;
+    std::map<std::pair<int, int>, sr_fbm_plan*> plans;
+    bool any_active() const {
+        for (size_t i = 0; i < layers.size(); ++i)
+            if (layers[i].active) return true;
+        return false;
+    }
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvent> events;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4 };
+
+struct Layout {
+    size_t in0, f0, trunk[3], xg[4], band64, bandg[4], gates, pooled, wdyn, fft, u1, band_u1, u2, u3, band_hr, outp;
+    size_t total;
+};
+
+size_t fft_ws_need(const sr_rrdbnet* net, int B, int H, int W) {
+    size_t need = 0;
+    const int C[3] = {net->nf > net->gc ? net->nf : net->gc, net->nf, net->nf};
+    for (int i = 0; i < 3; ++i) {
+        auto it = net->plans.find({H << i, W << i});
+        if (it == net->plans.end()) return 0;
+        const size_t b = sr_fbm_workspace_bytes(it->second, B, C[i]);
+        if (b > need) need = b;
+    }
+    return need;
+}
+
+Layout make_layout(const sr_rrdbnet* net, int dtype, int B, int H, int W) {
+    Layout L{};
+    const size_t es = dtype_size(dtype);
+    const size_t n1 = (size_t)B * H * W, n2 = 4 * n1, n4 = 16 * n1;
+    const bool act = net->any_active();
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.in0 = carve(n1 * net->cin0 * es);
+    L.f0 = carve(n1 * net->nf * es);
+    for (int i = 0; i < 3; ++i) L.trunk[i] = carve(n1 * net->nf * es);
+    for (int i = 0; i < 4; ++i) L.xg[i] = carve(n1 * net->gc * es);
+    L.u1 = carve(n2 * net->nf * es);
+    L.u2 = carve(n4 * net->nf * es);
+    L.u3 = carve(n4 * net->nf * es);
+    L.outp = carve(n4 * net->out_ch * es);
+    if (act) {
+        L.band64 = carve(3 * n1 * net->nf * es);
+        for (int i = 0; i < 4; ++i) L.bandg[i] = carve(3 * n1 * net->gc * es);
+        L.band_u1 = carve(3 * n2 * net->nf * es);
+        L.band_hr = carve(3 * n4 * net->nf * es);
+        L.gates = carve(n4 * 4 * sizeof(float));
+        const int cmax = net->nf + 4 * net->gc;
+        L.pooled = carve((size_t)B * cmax * sizeof(float));
+        L.wdyn = carve((size_t)B * 9 * net->nf * cmax * es);
+        L.fft = carve(fft_ws_need(net, B, H, W));
+    }
+    L.total = off;
+    return L;
+}
+
+struct Run {
+    sr_rrdbnet* net;
+    int dtype, B, H, W;
+    hipStream_t st;
+    char* ws;
+    Layout L;
+    size_t es;
+    int rc = SR_OK;
+
+    View view(size_t off, int C) const { return View{ws + off, C, 0, C}; }
+
+    void prof_begin(int group) {
+        if (!net->prof || rc != SR_OK) return;
+        if (net->ev_used == net->events.size()) {
+            ProfEvent e{};
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+            net->events.push_back(e);
+        }
+        net->events[net->ev_used].group = group;
+        (void)hipEventRecord(net->events[net->ev_used].a, st);
+    }
+    void prof_end() {
+        if (!net->prof || rc != SR_OK || net->ev_used >= net->events.size()) return;
+        (void)hipEventRecord(net->events[net->ev_used].b, st);
+        net->ev_used++;
+    }
+
+    sr_fbm_plan* plan(int res) {
+        auto it = net->plans.find({H << res, W << res});
+        return it == net->plans.end() ? nullptr : it->second;
+    }
+
+    // low-pass tensors + pooled means of `t` as seen by a conv at resolution `res`
+    void ensure_bands(Tensor& t, int res, int pooled_off) {
+        if (rc != SR_OK || t.bands_ready) return;
+        const int ups = res - t.res;
+        sr_fbm_plan* pl = plan(res);
+        if (!pl || ups < 0 || ups > 1) { rc = SR_ERR_STATE; return; }
+        float* pooled = (float*)(ws + L.pooled) + pooled_off;
+        prof_begin(G_LOWPASS);
+        rc = fbm_lowpass_launch(pl, dtype, B, t.x, ups, t.band[0], t.band[1], t.band[2], pooled,
+                                net->nf + 4 * net->gc, ws + L.fft, L.total - L.fft, st);
+        prof_end();
+        t.bands_ready = true;
+        t.bands_ups = ups;
+    }
+
+    // one conv layer: segs = virtual concat; conv runs at resolution `res`
+    void conv(int li, Tensor** segs, int nseg, int res, const Epilogue& ep_in, View out) {
+        if (rc != SR_OK) return;
+        const sr_layer_params& lp = net->layers[li];
+        const int Hc = H << res, Wc = W << res;
+        Concat c{};
+        c.nseg = nseg;
+        c.bands = lp.active ? 1 : 0;
+        c.ups = res - segs[0]->res;
+        int tot = 0;
+        for (int s = 0; s < nseg; ++s) {
+            if (lp.active) ensure_bands(*segs[s], res, tot);
+            c.x[s] = segs[s]->x;
+            c.l2[s] = segs[s]->band[0];
+            c.l4[s] = segs[s]->band[1];
+            c.l8[s] = segs[s]->band[2];
+            c.cstart[s] = tot;
+            tot += segs[s]->C;
+        }
+        for (int s = nseg; s <= SR_MAX_SEG; ++s) c.cstart[s] = tot;
+        c.ctot = tot;
+        if (rc != SR_OK) return;
+        if (tot != lp.cin || out.C != lp.cout) { rc = SR_ERR_ARG; return; }
+        Epilogue ep = ep_in;
+        ep.bias = lp.bias;
+        if (lp.active) {
+            float* gates = (float*)(ws + L.gates);
+            prof_begin(G_GATES);
+            rc = fbm_gates_launch(dtype, B, Hc, Wc, c, lp, gates, st);
+            prof_end();
+            if (rc != SR_OK) return;
+            prof_begin(G_WGEN);
+            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn, st);
+            prof_end();
+            if (rc != SR_OK) return;
+            prof_begin(G_CONV);
+            rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, lp.cout, ep, out, st);
+            prof_end();
+        } else {
+            if (!lp.wpacked) { rc = SR_ERR_STATE; return; }
+            prof_begin(G_CONV);
+            rc = conv3x3_launch(dtype, B, Hc, Wc, c, nullptr, lp.wpacked, 0, lp.cout, ep, out, st);
+            prof_end();
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int sr_rrdbnet_create(int num_in_ch, int num_out_ch, int scale, int num_feat, int num_block, int num_grow_ch,
+                                 sr_rrdbnet** out) {
+    SR_REQUIRE(out && num_in_ch > 0 && num_out_ch > 0 && num_feat > 0 && num_block >= 0 && num_grow_ch > 0);
+    SR_REQUIRE(scale == 1 || scale == 2 || scale == 4);
+    sr_rrdbnet* n = new sr_rrdbnet();
+    n->in_ch = num_in_ch;
+    n->out_ch = num_out_ch;
+    n->scale = scale;
+    n->nf = num_feat;
+    n->nb = num_block;
+    n->gc = num_grow_ch;
+    n->r = scale == 2 ? 2 : (scale == 1 ? 4 : 1);
+    n->cin0 = num_in_ch * n->r * n->r;
+    n->layers.resize(1 + 15 * (size_t)num_block + 5);
+    n->is_set.assign(n->layers.size(), 0);
+    *out = n;
+    return SR_OK;
+}
+
+extern "C" void sr_rrdbnet_destroy(sr_rrdbnet* n) {
+    if (!n) return;
+    for (auto& kv : n->plans) sr_fbm_plan_destroy(kv.second);
+    for (auto& e : n->events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    delete n;
+}
+
+extern "C" int sr_rrdbnet_num_layers(const sr_rrdbnet* n) { return n ? (int)n->layers.size() : SR_ERR_ARG; }
+
+extern "C" int sr_rrdbnet_set_layer(sr_rrdbnet* n, int index, const sr_layer_params* lp) {
+    SR_REQUIRE(n && lp && index >= 0 && index < (int)n->layers.size());
+    // expected shape of layer `index` in state_dict order
+    int cin, cout;
+    const int nbody = 15 * n->nb;
+    if (index == 0) { cin = n->cin0; cout = n->nf; }
+    else if (index <= nbody) {
+        const int k = (index - 1) % 5;  // conv1..conv5
+        cin = n->nf + k * n->gc;
+        cout = k == 4 ? n->nf : n->gc;
+    } else if (index < nbody + 5) { cin = n->nf; cout = n->nf; }
+    else { cin = n->nf; cout = n->out_ch; }
+    SR_REQUIRE(lp->cin == cin && lp->cout == cout);
+    // FDConv on the 1/3-channel head and tail never activates (min(c) <= 16); wide ones are not planned for
+    SR_REQUIRE(!(lp->active && (index == 0 || index == (int)n->layers.size() - 1)));
+    if (lp->active) {
+        SR_REQUIRE(lp->basis && lp->fc_w && lp->loc_w && lp->ln_w && lp->ln_b && lp->loc_taps >= 1);
+        for (int k = 0; k < 3; ++k) SR_REQUIRE(lp->gate_w[k] && lp->gate_b[k]);
+    } else {
+        SR_REQUIRE(lp->wpacked);
+    }
+    n->layers[index] = *lp;
+    n->is_set[index] = 1;
+    return SR_OK;
+}
+
+extern "C" int sr_rrdbnet_prepare(sr_rrdbnet* n, int Hin, int Win) {
+    SR_REQUIRE(n && Hin > 0 && Win > 0 && Hin % n->r == 0 && Win % n->r == 0);
+    if (!n->any_active()) return SR_OK;
+    const int H = Hin / n->r, W = Win / n->r;
+    for (int i = 0; i < 3; ++i) {
+        const std::pair<int, int> key(H << i, W << i);
+        if (n->plans.count(key)) continue;
+        sr_fbm_plan* pl = nullptr;
+        int rc = sr_fbm_plan_create(key.first, key.second, &pl);
+        if (rc != SR_OK) return rc;
+        n->plans[key] = pl;
+    }
+    return SR_OK;
+}
+
+extern "C" size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet* n, int dtype, int B, int Hin, int Win) {
+    if (!n || !dtype_ok(dtype) || B < 1 || Hin < 1 || Win < 1 || Hin % n->r || Win % n->r) return 0;
+    return make_layout(n, dtype, B, Hin / n->r, Win / n->r).total;
+}
+
+extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B, int Hin, int Win, const void* x, void* y,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    SR_REQUIRE(n && dtype_ok(dtype) && dtype_ok(io_dtype) && B > 0 && B <= 65535 && x && y && workspace);
+    SR_REQUIRE(Hin > 0 && Win > 0 && Hin % n->r == 0 && Win % n->r == 0);
+    SR_REQUIRE(((uintptr_t)workspace % 256) == 0);
+    for (size_t i = 0; i < n->layers.size(); ++i)
+        if (!n->is_set[i]) return SR_ERR_STATE;
+    const int H = Hin / n->r, W = Win / n->r;
+    const bool act = n->any_active();
+    if (act)
+        for (int i = 0; i < 3; ++i)
+            if (!n->plans.count({H << i, W << i})) return SR_ERR_STATE;
+    Run R;
+    R.net = n;
+    R.dtype = dtype;
+    R.B = B;
+    R.H = H;
+    R.W = W;
+    R.st = (hipStream_t)stream;
+    R.ws = (char*)workspace;
+    R.L = make_layout(n, dtype, B, H, W);
+    R.es = dtype_size(dtype);
+    if (workspace_bytes < R.L.total) return SR_ERR_WORKSPACE;
+    n->ev_used = 0;
+    const Layout& L = R.L;
+    const size_t es = R.es;
+    const size_t n1 = (size_t)B * H * W, n2 = 4 * n1, n4 = 16 * n1;
+    const int nf = n->nf, gc = n->gc;
+
+    auto with_bands = [&](Tensor& t, size_t band_off, size_t npix) {
+        for (int k = 0; k < 3; ++k) t.band[k] = View{R.ws + band_off + (size_t)k * npix * t.C * es, t.C, 0, t.C};
+    };
+
+    // ---- pack input (pixel_unshuffle folded) --------------------------------------------------
+    R.prof_begin(G_LAYOUT);
+    int rc = sr_pack_nchw(x, io_dtype, R.ws + L.in0, dtype, B, n->in_ch, Hin, Win, n->r, stream);
+    R.prof_end();
+    if (rc != SR_OK) return rc;
+
+    Tensor tin;
+    tin.C = n->cin0;
+    tin.x = R.view(L.in0, n->cin0);
+    Tensor f0;
+    f0.C = nf;
+    f0.x = R.view(L.f0, nf);
+    if (act) with_bands(f0, L.band64, n1);
+    Tensor trunk[3];
+    for (int i = 0; i < 3; ++i) {
+        trunk[i].C = nf;
+        trunk[i].x = R.view(L.trunk[i], nf);
+        if (act) with_bands(trunk[i], L.band64, n1);  // one 64-channel band set: only the current RDB input is live
+    }
+    Tensor xg[4];
+    for (int i = 0; i < 4; ++i) {
+        xg[i].C = gc;
+        xg[i].x = R.view(L.xg[i], gc);
+        if (act) with_bands(xg[i], L.bandg[i], n1);
+    }
+
+    int li = 0;
+    {
+        Tensor* s[1] = {&tin};
+        Epilogue ep{};
+        R.conv(li++, s, 1, 0, ep, f0.x);
+    }
+    Tensor* cur = &f0;
+    for (int blk = 0; blk < n->nb; ++blk) {
+        Tensor* blk_in = cur;
+        for (int j = 0; j < 3; ++j) {
+            Tensor* x0 = cur;
+            x0->bands_ready = false;  // the shared 64-channel band set now belongs to this RDB input
+            for (int i = 0; i < 4; ++i) xg[i].bands_ready = false;
+            Tensor* segs[5] = {x0, &xg[0], &xg[1], &xg[2], &xg[3]};
+            for (int k = 0; k < 4; ++k) {
+                Epilogue ep{};
+                ep.lrelu = 1;
+                R.conv(li++, segs, k + 1, 0, ep, xg[k].x);
+            }
+            Tensor* outp = nullptr;
+            for (int i = 0; i < 3; ++i)
+                if (&trunk[i] != x0 && &trunk[i] != blk_in) { outp = &trunk[i]; break; }
+            Epilogue ep{};
+            ep.r1 = x0->x;
+            ep.s1 = 0.2f;
+            if (j == 2) {
+                ep.r2 = blk_in->x;
+                ep.s2 = 0.2f;
+            }
+            R.conv(li++, segs, 5, 0, ep, outp->x);
+            cur = outp;
+        }
+    }
+    // conv_body: feat = f0 + conv_body(cur)
+    Tensor* g = nullptr;
+    for (int i = 0; i < 3; ++i)
+        if (&trunk[i] != cur) { g = &trunk[i]; break; }
+    {
+        cur->bands_ready = false;
+        Tensor* s[1] = {cur};
+        Epilogue ep{};
+        ep.r1 = f0.x;
+        ep.s1 = 1.0f;
+        R.conv(li++, s, 1, 0, ep, g->x);
+    }
+    // conv_up1 on nearest2x(g) at 2H x 2W
+    Tensor u1;
+    u1.C = nf;
+    u1.res = 1;
+    u1.x = R.view(L.u1, nf);
+    {
+        g->bands_ready = false;
+        if (act) with_bands(*g, L.band_u1, n2);
+        Tensor* s[1] = {g};
+        Epilogue ep{};
+        ep.lrelu = 1;
+        R.conv(li++, s, 1, 1, ep, u1.x);
+    }
+    // conv_up2 on nearest2x(u1) at 4H x 4W
+    Tensor u2;
+    u2.C = nf;
+    u2.res = 2;
+    u2.x = R.view(L.u2, nf);
+    {
+        if (act) with_bands(u1, L.band_hr, n4);
+        Tensor* s[1] = {&u1};
+        Epilogue ep{};
+        ep.lrelu = 1;
+        R.conv(li++, s, 1, 2, ep, u2.x);
+    }
+    // conv_hr, conv_last
+    Tensor u3;
+    u3.C = nf;
+    u3.res = 2;
+    u3.x = R.view(L.u3, nf);
+    {
+        if (act) with_bands(u2, L.band_hr, n4);
+        Tensor* s[1] = {&u2};
+        Epilogue ep{};
+        ep.lrelu = 1;
+        R.conv(li++, s, 1, 2, ep, u3.x);
+    }
+    {
+        Tensor* s[1] = {&u3};
+        if (act) with_bands(u3, L.band_hr, n4);
+        Epilogue ep{};
+        R.conv(li++, s, 1, 2, ep, R.view(L.outp, n->out_ch));
+    }
+    if (R.rc != SR_OK) return R.rc;
+    R.prof_begin(G_LAYOUT);
+    rc = sr_unpack_nhwc(R.ws + L.outp, dtype, y, io_dtype, B, n->out_ch, 4 * H, 4 * W, stream);
+    R.prof_end();
+    return rc;
+}
+
+extern "C" int sr_rrdbnet_profile(sr_rrdbnet* n, int enable) {
+    SR_REQUIRE(n);
+    n->prof = enable != 0;
+    n->ev_used = 0;
+    return SR_OK;
+}
+
+extern "C" int sr_rrdbnet_profile_read(sr_rrdbnet* n, float* ms5, long* launches5) {
+    SR_REQUIRE(n && ms5 && launches5);
+    for (int i = 0; i < 5; ++i) { ms5[i] = 0.f; launches5[i] = 0; }
+    for (size_t i = 0; i < n->ev_used; ++i) {
+        float ms = 0.f;
+        SR_HIP(hipEventSynchronize(n->events[i].b));
+        SR_HIP(hipEventElapsedTime(&ms, n->events[i].a, n->events[i].b));
+        ms5[n->events[i].group] += ms;
+        launches5[n->events[i].group] += 1;
+    }
+    return SR_OK;
+}

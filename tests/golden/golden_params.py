@@ -43,7 +43,7 @@ def fdconv_params(cin, cout, seed, kn=4, att=16, wscale=1.0):
     p['KSM_Local.conv.weight'] = 0.5 * f(cout * 9, 1, ksm_local_taps(cin))
     p['KSM_Local.norm.weight'] = 1 + 0.3 * f(cin)
     p['KSM_Local.norm.bias'] = 0.3 * f(cin)
-    return {k: np.ascontiguousarray(v) for k, v in p.items()}
+    return {k: (np.ascontiguousarray(v) if v.ndim else v) for k, v in p.items()}
 
 
 def plain_conv_params(cin, cout, seed, gain=1.0):

@@ -1,0 +1,153 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sr_amd.h declares, host-only
+logic (mask resize, argument validation, module construction / state_dict layout, tile geometry, sharding)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_params as gp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def L():
+    from super_resolution_amd.build import build
+    build(verbose=False)
+    from super_resolution_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, 'include', 'sr_amd.h')).read()
+    declared = set(re.findall(r'\b(sr_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert declared == set(L.HEADER_SYMBOLS), declared ^ set(L.HEADER_SYMBOLS)
+    lib = L.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.sr_version() >= 100
+    assert lib.sr_strerror(-1).decode().startswith('bad argument')
+
+
+def test_struct_sizes_match_header(L):
+    # ask the C compiler what the header's structs measure, and compare with the ctypes mirrors
+    import ctypes as C
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "sr_amd.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(sr_view), ' \
+          'sizeof(sr_concat), sizeof(sr_epilogue), sizeof(sr_layer_params));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 'a.c'), 'w').write(src)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'a.c'), '-o', os.path.join(d, 'a')])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(d, 'a')]).split()]
+    assert sizes == [C.sizeof(L.View), C.sizeof(L.Concat), C.sizeof(L.Epilogue), C.sizeof(L.LayerParams)]
+
+
+def test_masks_host_vs_reference_golden(L, golden):
+    g = golden['fbm_masks']
+    for key in g.files:
+        if not key.startswith('rows_'):
+            continue
+        n = int(key[5:])
+        rows = np.zeros(3 * n, np.uint8)
+        cols = np.zeros(3 * (n // 2 + 1), np.uint8)
+        L.check(L.lib().sr_fbm_masks_host(n, n, rows.ctypes.data, cols.ctypes.data))
+        assert np.array_equal(rows.reshape(3, n).astype(bool), g['rows_%d' % n]), n
+        assert np.array_equal(cols.reshape(3, -1).astype(bool), g['cols_%d' % n]), n
+
+
+def test_masks_host_vs_torch_interpolate_sweep(L):
+    from oracle import fdconv_ref as fr
+    for n in list(range(2, 200)) + [1000, 1044, 4095]:
+        rows = np.zeros(3 * n, np.uint8)
+        cols = np.zeros(3 * (n // 2 + 1), np.uint8)
+        L.check(L.lib().sr_fbm_masks_host(n, n, rows.ctypes.data, cols.ctypes.data))
+        rm, cm = fr.fbm_masks(n, n)
+        assert np.array_equal(rows.reshape(3, n).astype(bool), rm.numpy()), n
+        assert np.array_equal(cols.reshape(3, -1).astype(bool), cm.numpy()), n
+
+
+def test_argument_validation_without_gpu(L):
+    import ctypes as C
+    lib = L.lib()
+    assert lib.sr_pack_nchw(None, 0, None, 0, 1, 1, 1, 1, 1, None) == -1
+    assert lib.sr_fbm_workspace_bytes(None, 1, 1) == 0
+    assert lib.sr_fdconv_basis_workspace_bytes(32, 64) == 4 * 96 * 97 * 16
+    h = C.c_void_p()
+    assert lib.sr_rrdbnet_create(3, 3, 3, 64, 23, 32, C.byref(h)) == -1  # scale 3 does not exist
+    L.check(lib.sr_rrdbnet_create(1, 1, 4, 64, 23, 32, C.byref(h)))
+    assert lib.sr_rrdbnet_num_layers(h) == 351
+    lp = L.LayerParams()
+    lp.cin, lp.cout = 5, 64
+    assert lib.sr_rrdbnet_set_layer(h, 0, C.byref(lp)) == -1  # wrong shape for conv_first
+    assert lib.sr_rrdbnet_forward(h, 0, 0, 1, 8, 8, 1, 1, 256, 0, None) == -4  # layers not set
+    lib.sr_rrdbnet_destroy(h)
+
+
+def test_module_state_dict_layout():
+    from super_resolution_amd import FDConv, RRDBNet, replace_conv_with_fdconv
+    m = FDConv(64, 32, kernel_size=3, padding=1)
+    sd = m.state_dict()
+    want = gp.fdconv_params(64, 32, 0)
+    assert set(sd) == set(want) and len(sd) == 27
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(want[k].shape), k
+    assert 'indices' not in sd and tuple(m.indices.shape) == (1, 2, 4, 2328)
+    assert tuple(m.FBM.cached_masks.shape) == (3, 1, 64, 33)
+    assert isinstance(m, torch.nn.Conv2d) and m.in_channels == 64
+    net = replace_conv_with_fdconv(RRDBNet(1, 1, 4, 64, 1, 32))
+    ref = gp.rrdbnet_state(1, 1, 64, 1, 32, seed=7)
+    assert set(net.state_dict()) == set(ref)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+    plain = RRDBNet(3, 3, 4, 64, 23, 32)
+    assert len(plain.state_dict()) == 702
+    assert sum(p.numel() for p in plain.parameters()) == 16697987
+    with pytest.raises(NotImplementedError):
+        FDConv(64, 32, kernel_size=3, padding=1, kernel_num=8)
+    with pytest.raises(RuntimeError):
+        plain(torch.zeros(1, 3, 8, 8))  # CPU tensors are refused: there is no fallback path
+
+
+def test_fdconv_init_matches_reference_statistics():
+    """Same init scheme as the reference (FDConv.py:115-170, 285, 370): near-zero heads, kaiming filter_fc."""
+    from super_resolution_amd import FDConv
+    torch.manual_seed(0)
+    m = FDConv(64, 32, kernel_size=3, padding=1)
+    g = m.KSM_Global
+    assert g.spatial_fc.weight.abs().max() < 1e-5 and g.kernel_fc.weight.abs().max() < 1e-5
+    assert g.channel_fc.weight.abs().max() < 1e-5 and g.filter_fc.weight.std() > 0.05
+    assert torch.all(m.KSM_Local.conv.weight == 1e-6)
+    assert all(c.weight.abs().max() < 1e-5 and float(c.bias) == 0 for c in m.FBM.freq_weight_conv_list)
+    assert m.alpha == 64 and tuple(m.dft_weight.shape) == (1, 96, 97, 2)
+
+
+def test_tile_windows_and_sharding():
+    from super_resolution_amd import RealESRGANer
+    from oracle.realesrganer_ref import tile_windows
+
+    class Up(torch.nn.Module):
+        def forward(self, x):
+            return torch.nn.functional.interpolate(x, scale_factor=4, mode='nearest')
+
+    r = RealESRGANer(scale=4, model_path=None, model=Up(), tile=512, tile_pad=10, pre_pad=0, device=torch.device('cpu'))
+    r.img = torch.zeros(1, 3, 4096, 4096)
+    wins = r.tile_windows()
+    ref = tile_windows(4096, 4096, 512, 10)
+    assert len(wins) == 64 and [w[0] for w in wins] == [d['inp'] for d in ref]
+    sizes = sorted(((w[0][1] - w[0][0]), (w[0][3] - w[0][2])) for w in wins)
+    assert sizes.count((532, 532)) == 36 and sizes.count((522, 522)) == 4  # SURVEY 2.1 tile census
+    shards = [r.shard_of(wins, k, 8) for k in range(8)]
+    assert sorted(sum(shards, [])) == list(range(64)) and all(len(s) == 8 for s in shards)
+    area = lambda i: (wins[i][0][1] - wins[i][0][0]) * (wins[i][0][3] - wins[i][0][2])
+    loads = [sum(area(i) for i in s) for s in shards]
+    assert max(loads) / min(loads) < 1.02
+    # whole pipeline on the CPU with a stand-in network: tiled == whole for a pointwise model
+    img = gp.image_input((37, 53, 3), 5)
+    r = RealESRGANer(scale=4, model_path=None, model=Up(), tile=16, tile_pad=3, pre_pad=5, device=torch.device('cpu'))
+    out, mode = r.enhance((img * 255).astype(np.uint8))
+    assert mode == 'RGB' and out.shape == (148, 212, 3)
+    assert np.array_equal(out, np.repeat(np.repeat((img * 255).astype(np.uint8), 4, 0), 4, 1))

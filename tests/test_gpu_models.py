@@ -1,0 +1,228 @@
+"""GPU parity of the drop-in modules (FDConv, RRDBNet, RealESRGANer) against the reference's golden
+outputs and the CPU oracle.  Runs on the MI355X box (-m gpu); every forward goes through libsr_amd."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_params as gp
+from oracle import realesrganer_ref as rr
+from oracle.rrdbnet_ref import rrdbnet_forward
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4  # north_star: fp32 max-abs-err <= 1e-4
+PSNR_DELTA_DB = 0.05  # north_star: bf16 PSNR delta <= 0.05 dB
+
+
+def t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def psnr(a, b):
+    """train/test_optimized_model.py:107-114: 20*log10(1/sqrt(mse)) on [0,1] data."""
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 99.0 if mse == 0 else 20 * math.log10(1.0 / math.sqrt(mse))
+
+
+@pytest.fixture(scope='module')
+def sra():
+    import super_resolution_amd as m
+    from super_resolution_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return m
+
+
+def _layer_cases(golden):
+    out = []
+    for key in golden['fdconv_layers'].files:
+        if key.startswith('c') and key.endswith('.y'):
+            tag = key[:-2]
+            cin, cout, h, w = [int(s.lstrip('chw')) for s in tag.split('_')]
+            out.append((tag, cin, cout, h, w))
+    return out
+
+
+def test_fdconv_layers_vs_reference_golden(sra, golden):
+    """Every golden FDConv layer case (6 channel shapes, odd sizes, the small-plane branch) in fp32."""
+    g = golden['fdconv_layers']
+    mods = {}
+    worst = 0.0
+    for tag, cin, cout, h, w in _layer_cases(golden):
+        li = gp.LAYER_SHAPES.index((cin, cout))
+        if (cin, cout) not in mods:
+            m = sra.FDConv(cin, cout, kernel_size=3, stride=1, padding=1, bias=True)
+            m.load_state_dict(t(gp.fdconv_params(cin, cout, seed=100 + li)), strict=True)
+            mods[(cin, cout)] = m.eval().cuda()
+        x = torch.from_numpy(gp.signed_input((2, cin, h, w), seed=200 + li)).cuda()
+        with torch.no_grad():
+            y = mods[(cin, cout)](x).cpu().numpy()
+        err = np.abs(y - g[tag + '.y']).max()
+        worst = max(worst, err)
+        assert err < FP32_TOL, (tag, err)
+    print('worst fp32 FDConv layer error vs reference: %.3e' % worst)
+
+
+def test_fdconv_group_map_matches_reference(sra, golden):
+    for cin, cout in gp.LAYER_SHAPES:
+        m = sra.FDConv(cin, cout, kernel_size=3, padding=1)
+        assert np.array_equal(m.group_map().numpy(), golden['group_maps']['gmap_%d_%d' % (cin, cout)])
+
+
+def test_fdconv_thin_layer_is_plain_conv(sra):
+    m = sra.FDConv(1, 64, kernel_size=3, padding=1).eval().cuda()
+    assert not m.fdconv_active and 'weight' in m.state_dict() and 'dft_weight' not in m.state_dict()
+    x = torch.from_numpy(gp.signed_input((2, 1, 13, 9), 3)).cuda()
+    with torch.no_grad():
+        y = m(x)
+    ref = torch.nn.functional.conv2d(x.cpu(), m.weight.detach().cpu(), m.bias.detach().cpu(), padding=1)
+    assert (y.cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_fdconv_bf16_layer(sra, golden):
+    """bf16 storage + MFMA: error relative to the fp32 reference output stays at bf16 rounding level."""
+    cin, cout = 64, 32
+    m = sra.FDConv(cin, cout, kernel_size=3, padding=1)
+    m.load_state_dict(t(gp.fdconv_params(cin, cout, seed=100)), strict=True)
+    m = m.eval().cuda()
+    x = torch.from_numpy(gp.signed_input((2, cin, 40, 48), seed=200)).cuda()
+    with torch.no_grad():
+        y = m(x.to(torch.bfloat16)).float().cpu().numpy()
+    ref = golden['fdconv_layers']['c64_32_h40_w48.y']
+    rel = np.abs(y - ref).max() / np.abs(ref).max()
+    assert rel < 3e-2, rel
+
+
+def build_net(sra, args, sd, fdconv):
+    net = sra.RRDBNet(*args)
+    if fdconv:
+        net = sra.replace_conv_with_fdconv(net)
+    net.load_state_dict(sd, strict=True)
+    return net.eval().cuda()
+
+
+def test_rrdbnet_fdconv_one_block_vs_reference_golden(sra, golden):
+    sd = t(gp.rrdbnet_state(1, 1, 64, 1, 32, seed=7))
+    net = build_net(sra, (1, 1, 4, 64, 1, 32), sd, True)
+    assert len(net.state_dict()) == int(golden['rrdbnet_fdconv_1block']['n_keys'])
+    x = torch.from_numpy(gp.image_input((2, 1, 32, 32), seed=70)).cuda()
+    with torch.no_grad():
+        y = net(x).cpu().numpy()
+    ref = golden['rrdbnet_fdconv_1block']['y']
+    assert y.shape == (2, 1, 128, 128)
+    assert np.abs(y - ref).max() < FP32_TOL
+
+
+def test_rrdbnet_fdconv_three_blocks_odd_size_vs_oracle(sra):
+    sd = t(gp.rrdbnet_state(1, 1, 64, 3, 32, seed=8))
+    net = build_net(sra, (1, 1, 4, 64, 3, 32), sd, True)
+    x = torch.from_numpy(gp.image_input((1, 1, 29, 38), seed=71))
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+    ref = rrdbnet_forward(sd, x)
+    assert (y - ref).abs().max().item() < FP32_TOL
+
+
+def test_plain_rrdbnet_x4plus_shape_vs_oracle(sra):
+    """config 1 architecture (RealESRGAN_x4plus: RRDBNet(3,3,64,23,32)), fp32, on a 48x40 RGB input."""
+    sd = t(gp.rrdbnet_state(3, 3, 64, 23, 32, seed=11, fdconv=False, gain=0.5))
+    net = build_net(sra, (3, 3, 4, 64, 23, 32), sd, False)
+    x = torch.from_numpy(gp.image_input((1, 3, 48, 40), seed=72))
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+    ref = rrdbnet_forward(sd, x)
+    assert y.shape == (1, 3, 192, 160)
+    assert (y - ref).abs().max().item() < FP32_TOL
+    # bf16 MFMA path on the same network: PSNR of the output against the fp32 oracle output
+    with torch.no_grad():
+        yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
+    p = psnr(yb.clamp(0, 1), ref.clamp(0, 1))
+    print('plain RRDBNet bf16 vs fp32 oracle: PSNR %.1f dB' % p)
+    assert p > 40.0
+
+
+def test_rrdbnet_fdconv_bf16_psnr_delta(sra):
+    """bf16 criterion of north_star: PSNR delta <= 0.05 dB.  With no ground-truth image for random weights the
+    target is a synthetic 'clean' image; PSNR(out, target) is evaluated for the fp32 oracle output and for the
+    bf16 GPU output and the two must agree to 0.05 dB."""
+    sd = t(gp.rrdbnet_state(1, 1, 64, 2, 32, seed=12))
+    net = build_net(sra, (1, 1, 4, 64, 2, 32), sd, True)
+    x = torch.from_numpy(gp.image_input((2, 1, 32, 32), seed=73))
+    ref = rrdbnet_forward(sd, x)
+    with torch.no_grad():
+        yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
+    target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
+    p_ref = psnr(ref.clamp(0, 1), target)
+    p_bf = psnr(yb.clamp(0, 1), target)
+    p_direct = psnr(yb, ref)
+    print('PSNR vs target: fp32 oracle %.3f dB, bf16 GPU %.3f dB; bf16-vs-fp32 direct %.1f dB' % (p_ref, p_bf, p_direct))
+    assert abs(p_ref - p_bf) <= PSNR_DELTA_DB
+    assert p_direct > 35.0
+
+
+def test_scale2_network_pixel_unshuffle(sra, golden):
+    sd = t(gp.rrdbnet_state(12, 3, 8, 1, 4, seed=10, fdconv=False))
+    net = build_net(sra, (3, 3, 2, 8, 1, 4), sd, False)
+    img = gp.image_input((21, 33, 3), seed=92)
+    r = sra.RealESRGANer(scale=2, model_path=None, model=net, tile=0, pre_pad=0, half=False)
+    r.pre_process(img)
+    r.process()
+    out = r.post_process().cpu().numpy()
+    ref = golden['realesrganer']['x2_21x33']
+    assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-5
+
+
+def test_realesrganer_vs_reference_golden(sra, golden, tmp_path):
+    g = golden['realesrganer']
+    sd = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=9, fdconv=False))
+    ckpt = str(tmp_path / 'net.pth')
+    torch.save({'params': sd}, ckpt)
+    img = gp.image_input((50, 70, 3), seed=90)
+    for tag, tile, pad, pre in (('whole', 0, 10, 0), ('tile32', 32, 10, 0), ('tile32_pre7', 32, 10, 7), ('tile16_pad4', 16, 4, 3)):
+        r = sra.RealESRGANer(scale=4, model_path=ckpt, model=sra.RRDBNet(3, 3, 4, 8, 1, 4), tile=tile, tile_pad=pad,
+                             pre_pad=pre, half=False)
+        r.pre_process(img)
+        r.tile_process() if tile > 0 else r.process()
+        out = r.post_process().cpu().numpy()
+        assert np.abs(out - g['rgb50x70_' + tag]).max() < 1e-5, tag
+    # Real-ESRGAN-master/tests/test_utils.py:33-56
+    r = sra.RealESRGANer(scale=4, model_path=ckpt, model=sra.RRDBNet(3, 3, 4, 8, 1, 4), tile=10, tile_pad=10, pre_pad=2)
+    img12 = gp.image_input((12, 12, 3), seed=91)
+    r.pre_process(img12)
+    assert r.img.shape == (1, 3, 14, 14)
+    r.scale = 1
+    r.pre_process(img12)
+    assert r.img.shape == (1, 3, 16, 16)
+    assert np.array_equal(r.img.cpu().numpy(), g['t_pre_mod_img'])
+    r.scale = 4
+    r.pre_process(img12)
+    r.tile_process()
+    assert r.output.shape == (1, 3, 64, 64)
+    assert np.abs(r.output.cpu().numpy() - g['t_tile_out']).max() < 1e-5
+    r.mod_scale = 4
+    assert r.post_process().shape == (1, 3, 56, 56)
+
+
+def test_enhance_modes_vs_oracle(sra):
+    sd = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=9, fdconv=False))
+    net = build_net(sra, (3, 3, 4, 8, 1, 4), sd, False)
+    oracle_net = lambda z: rrdbnet_forward(sd, z)
+    cases = [((gp.image_input((9, 7, 3), 1) * 255).astype(np.uint8), dict(tile=0, pre_pad=2), 'RGB'),
+             ((gp.image_input((9, 7), 2) * 60000).astype(np.uint16), dict(tile=4, tile_pad=2, pre_pad=0), 'L'),
+             (gp.image_input((6, 5, 4), 3), dict(tile=0, pre_pad=0), 'RGBA')]
+    for img, kw, mode in cases:
+        r = sra.RealESRGANer(scale=4, model_path=None, model=net, half=False, **kw)
+        out, m = r.enhance(img, outscale=4)
+        ref, m2 = rr.enhance(oracle_net, img, 4, **{'tile_pad': 10, **kw})
+        assert m == m2 == mode and out.shape == ref.shape and out.dtype == ref.dtype
+        assert np.abs(out.astype(np.int64) - ref.astype(np.int64)).max() <= 1  # rounding of a 1e-5 float difference
+    with pytest.raises(NotImplementedError):
+        r.enhance(cases[0][0], outscale=2)
+
+
+def test_cpu_tensor_is_refused(sra):
+    net = sra.RRDBNet(3, 3, 4, 8, 1, 4)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 8, 8))

@@ -1,0 +1,338 @@
+"""GPU parity of every libsr_amd entry point against the CPU oracle (runs on the MI355X box: -m gpu).
+
+All calls go through the C ABI (ctypes).  fp32 tolerance is north_star's 1e-4 max-abs-err; bf16
+results are compared with a bf16-appropriate relative tolerance stated at each test.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_params as gp
+from oracle import fdconv_ref as fr
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def L():
+    from super_resolution_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return _lib
+
+
+def dev(t):
+    return t.to('cuda:0')
+
+
+def nhwc(t, dt=torch.float32):
+    return dev(t).permute(0, 2, 3, 1).contiguous().to(dt)
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def st(L):
+    return L.stream_ptr(torch.device('cuda:0'))
+
+
+def make_lp(L, sd, cin, cout, dtype, keep):
+    """sr_layer_params of an active FDConv layer from a numpy/torch state dict (+ basis via the library)."""
+    lib = L.lib()
+    d = {k: dev(torch.as_tensor(v)).contiguous() for k, v in sd.items()}
+    keep.append(d)
+    lp = L.LayerParams()
+    lp.cin, lp.cout, lp.active = cin, cout, 1
+    lp.loc_taps = d['KSM_Local.conv.weight'].shape[-1]
+    gmap = dev(fr.freq_group_map(cout, cin))
+    basis = torch.empty(4, cout, cin, 9, device='cuda:0')
+    ws = torch.empty(lib.sr_fdconv_basis_workspace_bytes(cout, cin), dtype=torch.uint8, device='cuda:0')
+    L.check(lib.sr_fdconv_basis(d['dft_weight'].data_ptr(), gmap.data_ptr(), fr.fdconv_alpha(cout, cin), cout, cin,
+                                basis.data_ptr(), ws.data_ptr(), ws.numel(), st(L)))
+    keep += [gmap, basis, ws]
+    p = lambda k: d[k].data_ptr()
+    lp.bias, lp.basis, lp.fc_w = p('bias'), basis.data_ptr(), p('KSM_Global.fc.weight')
+    lp.bn_w, lp.bn_b = p('KSM_Global.bn.weight'), p('KSM_Global.bn.bias')
+    lp.bn_rm, lp.bn_rv = p('KSM_Global.bn.running_mean'), p('KSM_Global.bn.running_var')
+    lp.relu_s, lp.relu_b = p('KSM_Global.relu.scale'), p('KSM_Global.relu.bias')
+    lp.ch_w, lp.ch_b = p('KSM_Global.channel_fc.weight'), p('KSM_Global.channel_fc.bias')
+    lp.fl_w, lp.fl_b = p('KSM_Global.filter_fc.weight'), p('KSM_Global.filter_fc.bias')
+    lp.sp_w, lp.sp_b = p('KSM_Global.spatial_fc.weight'), p('KSM_Global.spatial_fc.bias')
+    lp.kn_w, lp.kn_b = p('KSM_Global.kernel_fc.weight'), p('KSM_Global.kernel_fc.bias')
+    for i in range(3):
+        lp.gate_w[i] = p('FBM.freq_weight_conv_list.%d.weight' % i)
+        lp.gate_b[i] = p('FBM.freq_weight_conv_list.%d.bias' % i)
+    lp.loc_w, lp.ln_w, lp.ln_b = p('KSM_Local.conv.weight'), p('KSM_Local.norm.weight'), p('KSM_Local.norm.bias')
+    return lp, basis
+
+
+# ------------------------------------------------------------------------------------------ layout
+def test_pack_unpack_and_pixel_unshuffle(L):
+    from oracle.rrdbnet_ref import pixel_unshuffle
+    lib = L.lib()
+    x = torch.from_numpy(gp.signed_input((2, 3, 8, 12), 1))
+    for r in (1, 2, 4):
+        xd = dev(x)
+        out = torch.empty(2, 8 // r, 12 // r, 3 * r * r, device='cuda:0')
+        L.check(lib.sr_pack_nchw(xd.data_ptr(), 0, out.data_ptr(), 0, 2, 3, 8, 12, r, st(L)))
+        ref = pixel_unshuffle(x, r) if r > 1 else x
+        assert torch.equal(nchw(out), ref)
+    y = torch.empty(2, 3, 8, 12, device='cuda:0')
+    xn = nhwc(x)
+    L.check(lib.sr_unpack_nhwc(xn.data_ptr(), 0, y.data_ptr(), 0, 2, 3, 8, 12, st(L)))
+    assert torch.equal(y.cpu(), x)
+    # dtype conversion on the way in: fp32 -> bf16 is round-to-nearest-even like torch
+    out = torch.empty(2, 8, 12, 3, device='cuda:0', dtype=torch.bfloat16)
+    L.check(lib.sr_pack_nchw(dev(x).data_ptr(), 0, out.data_ptr(), 1, 2, 3, 8, 12, 1, st(L)))
+    assert torch.equal(out.cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ FBM
+def run_lowpass(L, x, dt, ups=0):
+    lib = L.lib()
+    B, Cc, H, W = x.shape
+    Ho, Wo = H << ups, W << ups
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(Ho, Wo, C.byref(plan)))
+    xn = nhwc(x, dt)
+    bands = [torch.full((B, Ho, Wo, Cc), float('nan'), device='cuda:0', dtype=dt) for _ in range(3)]
+    pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+    L.check(lib.sr_fbm_lowpass(plan, L.dtype_code(dt), B, L.view(xn), ups, L.view(bands[0]), L.view(bands[1]),
+                               L.view(bands[2]), pooled.data_ptr(), Cc, ws.data_ptr(), ws.numel(), st(L)))
+    torch.cuda.synchronize()
+    lib.sr_fbm_plan_destroy(plan)
+    return [nchw(b) for b in bands], pooled.cpu()
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 12, 12), (1, 5, 33, 35), (2, 32, 40, 48), (1, 64, 64, 64), (1, 8, 130, 77),
+                                   (1, 4, 58, 36), (1, 2, 128, 256)])
+def test_fbm_lowpass_fp32(L, shape):
+    x = torch.from_numpy(gp.signed_input(shape, 11))
+    bands, pooled = run_lowpass(L, x, torch.float32)
+    ref = fr.fbm_lowpass(x.double()).float()
+    for k in range(3):
+        err = (bands[k] - ref[k]).abs().max().item()
+        assert err < 2e-5, (shape, k, err)
+    assert (pooled - x.mean(dim=(2, 3))).abs().max().item() < 1e-6
+
+
+def test_fbm_lowpass_upsampled_and_bf16(L):
+    x = torch.from_numpy(gp.signed_input((2, 8, 20, 24), 12))
+    xu = F.interpolate(x, scale_factor=2, mode='nearest')
+    bands, pooled = run_lowpass(L, x, torch.float32, ups=1)
+    ref = fr.fbm_lowpass(xu.double()).float()
+    for k in range(3):
+        assert (bands[k] - ref[k]).abs().max().item() < 2e-5
+    assert (pooled - xu.mean(dim=(2, 3))).abs().max().item() < 1e-6
+    xb = x.to(torch.bfloat16)
+    bands, pooled = run_lowpass(L, xb.float(), torch.bfloat16)
+    ref = fr.fbm_lowpass(xb.double()).float()
+    for k in range(3):  # output rounded to bf16: half an ulp of |x| < 1
+        assert (bands[k] - ref[k]).abs().max().item() < 4e-3
+
+
+def test_fbm_masks_host_matches_golden(L, golden):
+    lib = L.lib()
+    g = golden['fbm_masks']
+    for n in (12, 33, 64, 77, 130, 512, 522, 532, 2088, 2128):
+        rows = np.zeros(3 * n, np.uint8)
+        cols = np.zeros(3 * (n // 2 + 1), np.uint8)
+        L.check(lib.sr_fbm_masks_host(n, n, rows.ctypes.data, cols.ctypes.data))
+        assert np.array_equal(rows.reshape(3, n).astype(bool), g['rows_%d' % n])
+        assert np.array_equal(cols.reshape(3, -1).astype(bool), g['cols_%d' % n])
+
+
+def test_fbm_gates(L):
+    lib = L.lib()
+    keep = []
+    cin, cout = 96, 32
+    sd = gp.fdconv_params(cin, cout, 5)
+    lp, _ = make_lp(L, sd, cin, cout, torch.float32, keep)
+    x = torch.from_numpy(gp.signed_input((2, cin, 21, 37), 13))
+    # the input is given as a concat of two views (64 + 32) to exercise the segment walk
+    a, b = nhwc(x[:, :64]), nhwc(x[:, 64:])
+    cc = L.Concat()
+    cc.nseg = 2
+    cc.x[0], cc.x[1] = L.view(a), L.view(b)
+    gates = torch.empty(2, 21, 37, 4, device='cuda:0')
+    L.check(lib.sr_fbm_gates(0, 2, 21, 37, C.byref(cc), C.byref(lp), gates.data_ptr(), st(L)))
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ref = fr.fbm_gates(x, [t['FBM.freq_weight_conv_list.%d.weight' % i] for i in range(3)],
+                       [t['FBM.freq_weight_conv_list.%d.bias' % i] for i in range(3)])
+    got = gates.cpu()[..., :3].permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ weights
+@pytest.mark.parametrize('cin,cout', gp.LAYER_SHAPES)
+def test_basis_and_weightgen(L, cin, cout):
+    lib = L.lib()
+    keep = []
+    sd = gp.fdconv_params(cin, cout, 21)
+    lp, basis = make_lp(L, sd, cin, cout, torch.float32, keep)
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ref_b = fr.spectral_bases(t['dft_weight'], fr.freq_group_map(cout, cin), fr.fdconv_alpha(cout, cin), cout, cin,
+                              torch.float64).float()
+    got_b = basis.cpu().view(4, cout, cin, 3, 3)
+    assert (got_b - ref_b).abs().max().item() < 1e-6 * max(1.0, ref_b.abs().max().item())
+    B = 3
+    pooled = torch.from_numpy(gp.signed_input((B, cin), 22))
+    ca, fa, sa, ka = fr.ksm_global(pooled, t)
+    hr = fr.ksm_local(pooled, t, cout)
+    ref_w = sa.view(B, 1, 1, 3, 3) * ca.view(B, 1, cin, 1, 1) * fa.view(B, cout, 1, 1, 1) * \
+        torch.einsum('bg,goiuv->boiuv', ka, ref_b) * hr
+    wd = torch.empty(B, 9, cout, cin, device='cuda:0')
+    pd = dev(pooled)
+    L.check(lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), wd.data_ptr(), st(L)))
+    got_w = wd.cpu().view(B, 3, 3, cout, cin).permute(0, 3, 4, 1, 2)
+    assert (got_w - ref_w).abs().max().item() < 2e-6 * max(1.0, ref_w.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------ conv
+def run_conv(L, dt, xs, w, bias=None, lrelu=0, r1=None, s1=0.0, r2=None, s2=0.0, bands=None, gates=None, ups=0,
+             per_sample=False):
+    """xs: list of NCHW tensors (virtual concat); w: (cout,cin,3,3) or (B,cout,cin,3,3)."""
+    lib = L.lib()
+    B = xs[0].shape[0]
+    H, W = xs[0].shape[2] << ups, xs[0].shape[3] << ups
+    cout = w.shape[-4]
+    cc = L.Concat()
+    cc.nseg, cc.ups = len(xs), ups
+    keep = []
+    for i, x in enumerate(xs):
+        t = nhwc(x, dt)
+        keep.append(t)
+        cc.x[i] = L.view(t)
+        if bands is not None:
+            cc.bands = 1
+            for name, src in zip(('l2', 'l4', 'l8'), bands[i]):
+                tb = nhwc(src, dt)
+                keep.append(tb)
+                getattr(cc, name)[i] = L.view(tb)
+    wk = (w if per_sample else w[None]).permute(0, 3, 4, 1, 2).reshape(-1, 9, cout, w.shape[-3])
+    wd = dev(wk).contiguous().to(dt)
+    ep = L.Epilogue()
+    if bias is not None:
+        bd = dev(bias)
+        keep.append(bd)
+        ep.bias = bd.data_ptr()
+    ep.lrelu = lrelu
+    if r1 is not None:
+        t = nhwc(r1, dt)
+        keep.append(t)
+        ep.r1, ep.s1 = L.view(t), s1
+    if r2 is not None:
+        t = nhwc(r2, dt)
+        keep.append(t)
+        ep.r2, ep.s2 = L.view(t), s2
+    gd = None
+    if gates is not None:
+        g4 = torch.cat([gates, torch.zeros_like(gates[:, :1])], 1)
+        gd = nhwc(g4)
+    out = torch.full((B, H, W, cout), float('nan'), device='cuda:0', dtype=dt)
+    L.check(lib.sr_conv3x3(L.dtype_code(dt), B, H, W, C.byref(cc), None if gd is None else gd.data_ptr(), wd.data_ptr(),
+                           9 * cout * w.shape[-3] if per_sample else 0, cout, C.byref(ep), L.view(out), st(L)))
+    torch.cuda.synchronize()
+    return nchw(out)
+
+
+def ref_conv(xs, w, bias=None, lrelu=0, r1=None, s1=0.0, r2=None, s2=0.0, bands=None, gates=None, ups=0,
+             per_sample=False):
+    x = torch.cat(xs, 1).double()
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    if bands is not None:
+        l2, l4, l8 = [torch.cat([b[k] for b in bands], 1).double() for k in range(3)]
+        g = gates.double()
+        x = g[:, 0:1] * x + (g[:, 1:2] - g[:, 0:1]) * l2 + (g[:, 2:3] - g[:, 1:2]) * l4 + (1 - g[:, 2:3]) * l8
+    if per_sample:
+        y = torch.stack([F.conv2d(x[i:i + 1], w[i].double(), padding=1)[0] for i in range(x.shape[0])])
+    else:
+        y = F.conv2d(x, w.double(), padding=1)
+    if bias is not None:
+        y = y + bias.double().view(1, -1, 1, 1)
+    if lrelu:
+        y = F.leaky_relu(y, 0.2)
+    if r1 is not None:
+        y = y * s1 + r1.double()
+    if r2 is not None:
+        y = y * s2 + r2.double()
+    return y.float()
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy(gp.signed_input(shape, seed)) * scale
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(3, 8, 9, 11), (8, 3, 17, 16), (64, 1, 20, 35), (12, 4, 33, 18), (20, 24, 16, 16)])
+def test_conv_generic_fp32(L, cin, cout, h, w):
+    x = rnd((2, cin, h, w), 31)
+    wt = rnd((cout, cin, 3, 3), 32, 0.2)
+    b = rnd((cout,), 33)
+    r1 = rnd((2, cout, h, w), 34)
+    kw = dict(bias=b, lrelu=1, r1=r1, s1=0.2)
+    got = run_conv(L, torch.float32, [x], wt, **kw)
+    assert (got - ref_conv([x], wt, **kw)).abs().max().item() < 1e-5
+
+
+def test_conv_generic_fp32_concat_bands_persample_ups(L):
+    B, h, w = 2, 10, 14
+    xs = [rnd((B, 16, h, w), 41), rnd((B, 8, h, w), 42)]
+    H, W = 2 * h, 2 * w
+    bands = [[rnd((B, x.shape[1], H, W), 43 + 3 * i + k) for k in range(3)] for i, x in enumerate(xs)]
+    gates = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(5)) * 2
+    wt = rnd((B, 24, 24, 3, 3), 50, 0.2)
+    kw = dict(bias=rnd((24,), 51), bands=bands, gates=gates, ups=1, per_sample=True, r1=rnd((B, 24, H, W), 52), s1=0.2,
+              r2=rnd((B, 24, H, W), 53), s2=0.2)
+    got = run_conv(L, torch.float32, xs, wt, **kw)
+    assert (got - ref_conv(xs, wt, **kw)).abs().max().item() < 1e-5
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(32, 32, 16, 32), (64, 32, 19, 45), (64, 64, 33, 70), (96, 32, 40, 48), (192, 64, 17, 31)])
+def test_conv_mfma_bf16_plain(L, cin, cout, h, w):
+    """MFMA kernel against an fp64 conv of the same bf16-rounded operands: only fp32 accumulation order and the
+    final bf16 rounding differ -> tolerance 2^-8 relative to the output magnitude."""
+    B = 2
+    segs = [64] + [32] * ((cin - 64) // 32) if cin >= 64 else [cin]
+    xs = [bf(rnd((B, c, h, w), 60 + i)) for i, c in enumerate(segs)]
+    wt = bf(rnd((cout, cin, 3, 3), 70, 0.1))
+    b = rnd((cout,), 71)
+    r1 = bf(rnd((B, cout, h, w), 72))
+    kw = dict(bias=b, lrelu=1, r1=r1, s1=0.2)
+    got = run_conv(L, torch.bfloat16, xs, wt, **kw)
+    ref = ref_conv(xs, wt, **kw)
+    tol = 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < tol
+    # and the VALU kernel on the same bf16 data agrees too
+    L.lib().sr_debug_force_generic_conv(1)
+    try:
+        got2 = run_conv(L, torch.bfloat16, xs, wt, **kw)
+    finally:
+        L.lib().sr_debug_force_generic_conv(0)
+    assert (got2 - ref).abs().max().item() < tol
+
+
+def test_conv_mfma_bf16_bands_persample_ups(L):
+    B, h, w = 2, 12, 20
+    xs = [bf(rnd((B, 64, h, w), 80)), bf(rnd((B, 32, h, w), 81))]
+    H, W = 2 * h, 2 * w
+    bands = [[bf(rnd((B, x.shape[1], H, W), 82 + 3 * i + k)) for k in range(3)] for i, x in enumerate(xs)]
+    gates = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(6)) * 2
+    wt = bf(rnd((B, 64, 96, 3, 3), 90, 0.1))
+    kw = dict(bias=rnd((64,), 91), bands=bands, gates=gates, ups=1, per_sample=True, r1=bf(rnd((B, 64, H, W), 92)), s1=0.2,
+              r2=bf(rnd((B, 64, H, W), 93)), s2=0.2)
+    got = run_conv(L, torch.bfloat16, xs, wt, **kw)
+    ref = ref_conv(xs, wt, **kw)
+    # the modulated operand is rounded to bf16 once more before the MFMA: 2^-7 relative
+    assert (got - ref).abs().max().item() < 2.0 ** -7 * max(1.0, ref.abs().max().item())
