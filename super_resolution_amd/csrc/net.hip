@@ -296,7 +296,6 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     R.L = make_layout(n, dtype, B, H, W);
     R.es = dtype_size(dtype);
     if (workspace_bytes < R.L.total) return SR_ERR_WORKSPACE;
-    n->ev_used = 0;
     const Layout& L = R.L;
     const size_t es = R.es;
     const size_t n1 = (size_t)B * H * W, n2 = 4 * n1, n4 = 16 * n1;
