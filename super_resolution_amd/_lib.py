@@ -73,10 +73,11 @@ _SIGS = {
     'sr_rrdbnet_profile': (C.c_int, [C.c_void_p, C.c_int]),
     'sr_rrdbnet_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]),
     'sr_debug_force_generic_conv': (None, [C.c_int]),
+    'sr_debug_force_generic_fft': (None, [C.c_int]),
 }
 
 # every symbol include/sr_amd.h declares (the debug hook is not part of the header)
-HEADER_SYMBOLS = [n for n in _SIGS if n != 'sr_debug_force_generic_conv']
+HEADER_SYMBOLS = [n for n in _SIGS if not n.startswith('sr_debug_')]
 
 _lib = None
 

@@ -21,21 +21,7 @@
 
 #include "common.h"
 
-struct sr_fbm_plan {
-    int H, W;
-    int nfW, nfH;
-    int radW[24], radH[24];
-    int Pw, Ph;            // channel pairs per workgroup in the row / column passes
-    int n[3];              // kept full-spectrum columns for k=2,4,8
-    float2* tw_w;          // device: exp(-2*pi*i*j/W)
-    float2* tw_h;          // device: exp(-2*pi*i*j/H)
-    int* cols;             // device: [n[0]] kept column index (mask k=2), ascending
-    int* colinfo;          // device: [n[0]][4] = {variant, index in k=4 list or -1, index in k=8 list or -1, 0}
-    int* cols4;            // device: [n[1]]
-    int* cols8;            // device: [n[2]]
-    float* rowmask;        // device: [3 masks][3 variants][H]
-    void* dev_block;       // one allocation backing all of the above
-};
+#include "fbm_plan.h"
 
 namespace sr {
 
@@ -266,6 +252,8 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
     }
 }
 
+int g_force_generic_fft = 0;  // test hook
+
 static Radix make_radix(const int* r, int nf) {
     Radix x{};
     x.nf = nf;
@@ -278,6 +266,10 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     const int H = pl->H, W = pl->W, C = x.C;
     const int PT = (C + 1) / 2;
     if (ws_bytes < sr_fbm_workspace_bytes(pl, B, C)) return SR_ERR_WORKSPACE;
+    if (!g_force_generic_fft) {
+        const int rc = fbm_lowpass_pow2(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st);
+        if (rc != SR_NOT_ELIGIBLE) return rc;
+    }
     const int n2 = pl->n[0], n4 = pl->n[1], n8 = pl->n[2];
     float2* t1 = (float2*)ws;
     float2* y2 = t1 + (size_t)B * n2 * H * PT;
@@ -316,6 +308,8 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 
 using namespace sr;
 
+extern "C" void sr_debug_force_generic_fft(int on) { sr::g_force_generic_fft = on; }
+
 extern "C" int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host) {
     SR_REQUIRE(H > 0 && W > 0 && rows_host && cols_host);
     resized_masks(H, W, rows_host, cols_host);
@@ -343,6 +337,16 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
             if (cols[k * wh + ch]) lists[k].push_back(c);
         }
     for (int k = 0; k < 3; ++k) pl->n[k] = (int)lists[k].size();
+    pl->contiguous = 1;
+    for (int k = 0; k < 3; ++k) {
+        int a = 0;
+        while (a <= W / 2 && cols[k * wh + a]) ++a;  // prefix of kept half-spectrum columns
+        pl->half[k] = a;
+        std::vector<int> want;
+        for (int c = 0; c < W; ++c)
+            if (c < a || c > W - a) want.push_back(c);
+        if (want != lists[k] || a < 1 || 2 * a - 1 > W) pl->contiguous = 0;
+    }
     if (pl->n[0] < 1) { free(pl); return SR_ERR_ARG; }
     std::vector<int> info(4 * lists[0].size());
     for (size_t i = 0; i < lists[0].size(); ++i) {

@@ -1,0 +1,380 @@
+// FBM low-pass planes, power-of-two fast path (64 <= H, W <= 2048).
+//
+// Same three-kernel decomposition as fbm.hip (rows forward -> columns forward/mask/inverse ->
+// rows inverse, two channels per complex signal, channel pairs on consecutive lanes), but the FFT
+// is a register-blocked Stockham: every thread owns whole radix-8/4/2 butterflies, a pass is
+//   [barrier] read R points per butterfly -> twiddle -> DFT_R in registers -> [barrier] write,
+// in place in one LDS buffer of N x P complex (64 KiB), with the first pass fed straight from
+// global memory and the last pass stored straight to global memory (no staging copies):
+//   rows_fwd : reads the activation row (bf16/fp32 channel pairs), writes only the kept columns;
+//   cols     : forward along H, then keeps each thread's first-pass operands of the spectrum in
+//              registers so the three masked inverse transforms reuse one LDS buffer;
+//   rows_inv : reads the sparse kept columns (zero elsewhere), writes the low-pass rows in the
+//              activation dtype.
+// Kept columns are the two contiguous runs [0, half) and (N - half, N) of the box masks.
+#include "common.h"
+#include "fbm_plan.h"
+
+namespace sr {
+namespace fast {
+
+constexpr int THREADS = 256;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -i (forward) or +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 rot90(float2 a) {
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+template <int R, bool INV>
+struct Dft;
+
+template <bool INV>
+struct Dft<2, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[2]) {
+        const float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <bool INV>
+struct Dft<4, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[4]) {
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        const float2 t2 = cadd(v[1], v[3]), t3 = rot90<INV>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[2] = csub(t0, t2);
+        v[3] = csub(t1, t3);
+    }
+};
+
+template <bool INV>
+struct Dft<8, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[8]) {
+        float2 e[4] = {v[0], v[2], v[4], v[6]};
+        float2 o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4, INV>::run(e);
+        Dft<4, INV>::run(o);
+        const float h = 0.70710678118654752440f;
+        // w8^u * o[u], w8 = exp(-+ 2 pi i / 8)
+        const float2 o1 = INV ? make_float2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y))
+                              : make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+        const float2 o2 = rot90<INV>(o[2]);
+        const float2 o3 = INV ? make_float2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y))
+                              : make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+        v[0] = cadd(e[0], o[0]);
+        v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], o1);
+        v[5] = csub(e[1], o1);
+        v[2] = cadd(e[2], o2);
+        v[6] = csub(e[2], o2);
+        v[3] = cadd(e[3], o3);
+        v[7] = csub(e[3], o3);
+    }
+};
+
+constexpr int pick_radix(int m) { return (m % 8 == 0 && m != 16) ? 8 : (m % 4 == 0 ? 4 : 2); }
+constexpr int first_radix(int n) { return pick_radix(n); }
+
+// One Stockham pass.  load(idx, p) / store(idx, p, v) address point idx of signal p.
+template <int N, int P, int R, int NS, bool INV, bool LOAD_LDS, bool STORE_LDS, typename LoadF, typename StoreF>
+__device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load, StoreF store) {
+    constexpr int NB = N / R * P;
+    constexpr int IT = (NB + THREADS - 1) / THREADS;
+    constexpr int NR = N / R;
+    constexpr int TSTEP = N / (NS * R);
+    float2 v[IT][R];
+    if (LOAD_LDS) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int i = threadIdx.x + q * THREADS;
+        if (NB % THREADS != 0 && i >= NB) continue;
+        const int p = i % P, j = i / P;
+        const int k = j % NS;
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[q][t] = load(j + t * NR, p, q, t);
+        if (NS > 1) {
+#pragma unroll
+            for (int t = 1; t < R; ++t) {
+                float2 w = twl[k * t * TSTEP];
+                if (INV) w.y = -w.y;
+                v[q][t] = cmulf(v[q][t], w);
+            }
+        }
+        Dft<R, INV>::run(v[q]);
+    }
+    if (STORE_LDS) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int i = threadIdx.x + q * THREADS;
+        if (NB % THREADS != 0 && i >= NB) continue;
+        const int p = i % P, j = i / P;
+        const int k = j % NS;
+        const int base = (j / NS) * NS * R + k;
+#pragma unroll
+        for (int u = 0; u < R; ++u) store(base + u * NS, p, v[q][u]);
+    }
+}
+
+// All passes of a length-N transform: first pass loads through `lf`, last pass stores through `sl`,
+// everything in between lives in `buf` (N x P complex, in place).
+// LAST_LDS: the caller's `sl` writes into `buf` (needs the read/write barrier).
+template <int N, int P, bool INV, int NS, bool LAST_LDS, typename LoadFirst, typename StoreLast>
+__device__ __forceinline__ void fft(float2* __restrict__ buf, const float2* __restrict__ twl, LoadFirst lf, StoreLast sl) {
+    constexpr int M = N / NS;
+    constexpr int R = pick_radix(M);
+    constexpr bool first = (NS == 1), last = (M == R);
+    auto lds_load = [&](int idx, int p, int, int) { return buf[idx * P + p]; };
+    auto lds_store = [&](int idx, int p, float2 v) { buf[idx * P + p] = v; };
+    if constexpr (first && last)
+        pass<N, P, R, NS, INV, false, true>(twl, lf, sl);
+    else if constexpr (first)
+        pass<N, P, R, NS, INV, false, true>(twl, lf, lds_store);
+    else if constexpr (last)
+        pass<N, P, R, NS, INV, true, LAST_LDS>(twl, lds_load, sl);
+    else
+        pass<N, P, R, NS, INV, true, true>(twl, lds_load, lds_store);
+    if constexpr (!last) fft<N, P, INV, NS * R, LAST_LDS>(buf, twl, lf, sl);
+}
+
+extern __shared__ __attribute__((aligned(16))) char smem_fast[];
+
+template <int N>
+__device__ __forceinline__ const float2* stage_twiddles(const float2* __restrict__ tw, float2* twl) {
+    for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = tw[i];
+    __syncthreads();
+    return twl;
+}
+
+template <typename T>
+struct Pair;
+template <>
+struct Pair<float> {
+    static __device__ __forceinline__ float2 ld(const float* p) { return *(const float2*)p; }
+    static __device__ __forceinline__ void st(float* p, float2 v) { *(float2*)p = v; }
+};
+template <>
+struct Pair<bf16_t> {
+    static __device__ __forceinline__ float2 ld(const bf16_t* p) {
+        const uint32_t u = *(const uint32_t*)p;
+        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, float2 v) {
+        *(uint32_t*)p = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    }
+};
+
+// position of full-spectrum column c in the kept list [0,a) u (N-a, N), or -1
+template <int N>
+__device__ __forceinline__ int kept_pos(int c, int a) {
+    return c < a ? c : (c > N - a ? c - (N - (2 * a - 1)) : -1);
+}
+
+// ---- rows forward -------------------------------------------------------------------------
+template <typename T, int N, int P>
+__global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int PT, const float2* __restrict__ tw,
+                                                    int a2, float2* __restrict__ t1) {
+    float2* buf = (float2*)smem_fast;
+    const float2* twl = stage_twiddles<N>(tw, buf + N * P);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int p0 = blockIdx.y * P;
+    const int n2 = 2 * a2 - 1;
+    const int Ws = N >> ups;
+    const T* row = (const T*)x.p + ((long)b * (H >> ups) + (h >> ups)) * Ws * x.ld + x.c0 + 2 * p0;
+    auto lf = [&](int idx, int p, int, int) {
+        return (p0 + p < PT) ? Pair<T>::ld(row + (long)(idx >> ups) * x.ld + 2 * p) : make_float2(0.f, 0.f);
+    };
+    float2* out = t1 + ((long)b * n2 * H + h) * PT + p0;
+    auto sl = [&](int idx, int p, float2 v) {
+        const int pos = kept_pos<N>(idx, a2);
+        if (pos >= 0 && p0 + p < PT) out[(long)pos * H * PT + p] = v;
+    };
+    fft<N, P, false, 1, false>(buf, twl, lf, sl);
+}
+
+// ---- columns: forward, mask, inverse x3 ------------------------------------------------------
+template <int N, int P>
+__global__ __launch_bounds__(THREADS) void cols(int W, int PT, const float2* __restrict__ tw, int a2, int a4, int a8,
+                                                const float* __restrict__ rowmask, const float2* __restrict__ t1,
+                                                float2* __restrict__ y2, float2* __restrict__ y4,
+                                                float2* __restrict__ y8, float* __restrict__ pooled, int pooled_ld,
+                                                int C) {
+    constexpr int H = N;
+    float2* buf = (float2*)smem_fast;
+    const float2* twl = stage_twiddles<N>(tw, buf + N * P);
+    const int n2 = 2 * a2 - 1;
+    const int b = blockIdx.x / n2, idx = blockIdx.x % n2;
+    const int p0 = blockIdx.y * P;
+    const int col = idx < a2 ? idx : idx + (W - n2);  // full-spectrum column of this block
+    const float2* src = t1 + ((long)b * n2 + idx) * H * PT + p0;
+    auto lf = [&](int h, int p, int, int) { return (p0 + p < PT) ? src[(long)h * PT + p] : make_float2(0.f, 0.f); };
+    auto s_lds = [&](int r, int p, float2 v) { buf[r * P + p] = v; };
+    // forward: the last pass stores back into LDS
+    fft<N, P, false, 1, true>(buf, twl, lf, s_lds);
+    __syncthreads();
+    if (pooled && idx == 0 && threadIdx.x < P && p0 + threadIdx.x < PT) {
+        const int c = 2 * (p0 + threadIdx.x);
+        const float inv = 1.0f / ((float)H * (float)W);
+        if (c < C) pooled[(long)b * pooled_ld + c] = buf[threadIdx.x].x * inv;
+        if (c + 1 < C) pooled[(long)b * pooled_ld + c + 1] = buf[threadIdx.x].y * inv;
+    }
+    // keep this thread's first-pass operands of the spectrum in registers
+    constexpr int R0 = first_radix(N);
+    constexpr int NB = N / R0 * P;
+    constexpr int IT = (NB + THREADS - 1) / THREADS;
+    float2 sreg[IT][R0];
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int i = threadIdx.x + q * THREADS;
+        const int p = i % P, j = i / P;
+#pragma unroll
+        for (int t = 0; t < R0; ++t)
+            sreg[q][t] = (NB % THREADS == 0 || i < NB) ? buf[(j + t * (N / R0)) * P + p] : make_float2(0.f, 0.f);
+    }
+    const int variant = (col == 0 || 2 * col == W) ? 2 : (2 * col < W ? 0 : 1);
+    const int ak[3] = {a2, a4, a8};
+    float2* ys[3] = {y2, y4, y8};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = ak[k];
+        const int nk = 2 * a - 1;
+        const int pos = col < a ? col : (col > W - a ? col - (W - nk) : -1);
+        if (pos < 0) continue;  // block-uniform
+        const float* rm = rowmask + (k * 3 + variant) * H;
+        // the first inverse pass takes the saved operands, scaled by the row mask
+        auto lm = [&](int r, int, int q, int t) {
+            const float m = rm[r];
+            return make_float2(sreg[q][t].x * m, sreg[q][t].y * m);
+        };
+        float2* y = ys[k] + ((long)b * H * nk + pos) * PT + p0;
+        auto sl = [&](int h, int p, float2 v) {
+            if (p0 + p < PT) y[(long)h * nk * PT + p] = v;
+        };
+        fft<N, P, true, 1, false>(buf, twl, lm, sl);
+    }
+}
+
+// ---- rows inverse -------------------------------------------------------------------------
+template <typename T, int N, int P>
+__global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, int H, int PT,
+                                                    const float2* __restrict__ tw, int a2, int a4, int a8,
+                                                    const float2* __restrict__ y2, const float2* __restrict__ y4,
+                                                    const float2* __restrict__ y8) {
+    float2* buf = (float2*)smem_fast;
+    const float2* twl = stage_twiddles<N>(tw, buf + N * P);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int p0 = blockIdx.y * P;
+    const float norm = 1.0f / ((float)H * (float)N);
+    const int ak[3] = {a2, a4, a8};
+    const float2* ys[3] = {y2, y4, y8};
+    const View outs[3] = {l2, l4, l8};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = ak[k];
+        const int nk = 2 * a - 1;
+        const float2* yr = ys[k] + ((long)b * H + h) * nk * PT + p0;
+        auto lf = [&](int c, int p, int, int) {
+            const int pos = kept_pos<N>(c, a);
+            return (pos >= 0 && p0 + p < PT) ? yr[(long)pos * PT + p] : make_float2(0.f, 0.f);
+        };
+        T* row = (T*)outs[k].p + ((long)b * H + h) * N * outs[k].ld + outs[k].c0 + 2 * p0;
+        const int ld = outs[k].ld;
+        auto sl = [&](int w, int p, float2 v) {
+            if (p0 + p < PT) Pair<T>::st(row + (long)w * ld + 2 * p, make_float2(v.x * norm, v.y * norm));
+        };
+        fft<N, P, true, 1, false>(buf, twl, lf, sl);
+    }
+}
+
+// ---- host dispatch ---------------------------------------------------------------------------
+constexpr int pairs_for(int n) { return n <= 512 ? 16 : (n == 1024 ? 8 : 4); }
+
+template <typename T, int N>
+static int launch_rows_fwd(View x, int ups, int B, int H, int PT, const sr_fbm_plan* pl, float2* t1, hipStream_t st) {
+    constexpr int P = pairs_for(N);
+    const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
+    SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rows_fwd<T, N, P><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, pl->tw_w, pl->half[0], t1);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+template <typename T, int N>
+static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, const sr_fbm_plan* pl, const float2* y2,
+                           const float2* y4, const float2* y8, hipStream_t st) {
+    constexpr int P = pairs_for(N);
+    const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
+    SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rows_inv<T, N, P><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, pl->tw_w, pl->half[0],
+                                                                   pl->half[1], pl->half[2], y2, y4, y8);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+template <int N>
+static int launch_cols(int B, int W, int PT, int C, const sr_fbm_plan* pl, const float2* t1, float2* y2, float2* y4,
+                       float2* y8, float* pooled, int pooled_ld, hipStream_t st) {
+    constexpr int P = pairs_for(N);
+    const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
+    SR_HIP(hipFuncSetAttribute((const void*)cols<N, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cols<N, P><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, pl->tw_h, pl->half[0], pl->half[1], pl->half[2],
+                                                                    pl->rowmask, t1, y2, y4, y8, pooled, pooled_ld, C);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+static bool pow2_ok(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; }
+
+#define SR_DISPATCH_N(n, CALL)            \
+    switch (n) {                          \
+        case 64: { constexpr int NN = 64; CALL; } break;     \
+        case 128: { constexpr int NN = 128; CALL; } break;   \
+        case 256: { constexpr int NN = 256; CALL; } break;   \
+        case 512: { constexpr int NN = 512; CALL; } break;   \
+        case 1024: { constexpr int NN = 1024; CALL; } break; \
+        case 2048: { constexpr int NN = 2048; CALL; } break; \
+        default: return SR_NOT_ELIGIBLE;  \
+    }
+
+}  // namespace fast
+
+int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
+                     int pooled_ld, void* ws, hipStream_t st) {
+    using namespace fast;
+    const int H = pl->H, W = pl->W, C = x.C;
+    if (!pl->contiguous || !pow2_ok(H) || !pow2_ok(W) || (C & 1)) return SR_NOT_ELIGIBLE;
+    // pair loads / stores need 2-element alignment of every view
+    const View* vs[4] = {&x, &l2, &l4, &l8};
+    const size_t es = dtype_size(dtype);
+    for (const View* v : vs)
+        if ((v->ld & 1) || (v->c0 & 1) || ((uintptr_t)v->p % (2 * es))) return SR_NOT_ELIGIBLE;
+    const int PT = C / 2;
+    const int n2 = pl->n[0], n4 = pl->n[1];
+    float2* t1 = (float2*)ws;
+    float2* y2 = t1 + (size_t)B * n2 * H * PT;
+    float2* y4 = y2 + (size_t)B * H * n2 * PT;
+    float2* y8 = y4 + (size_t)B * H * n4 * PT;
+    int rc = SR_OK;
+    if (dtype == SR_F32) {
+        SR_DISPATCH_N(W, rc = (launch_rows_fwd<float, NN>(x, ups, B, H, PT, pl, t1, st)));
+    } else {
+        SR_DISPATCH_N(W, rc = (launch_rows_fwd<bf16_t, NN>(x, ups, B, H, PT, pl, t1, st)));
+    }
+    if (rc != SR_OK) return rc;
+    SR_DISPATCH_N(H, rc = (launch_cols<NN>(B, W, PT, C, pl, t1, y2, y4, y8, pooled, pooled_ld, st)));
+    if (rc != SR_OK) return rc;
+    if (dtype == SR_F32) {
+        SR_DISPATCH_N(W, rc = (launch_rows_inv<float, NN>(l2, l4, l8, B, H, PT, pl, y2, y4, y8, st)));
+    } else {
+        SR_DISPATCH_N(W, rc = (launch_rows_inv<bf16_t, NN>(l2, l4, l8, B, H, PT, pl, y2, y4, y8, st)));
+    }
+    return rc;
+}
+}  // namespace sr

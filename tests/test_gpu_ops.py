@@ -123,6 +123,36 @@ def test_fbm_lowpass_fp32(L, shape):
     assert (pooled - x.mean(dim=(2, 3))).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 64, 64), (1, 6, 128, 64), (1, 34, 64, 256), (1, 64, 512, 512), (1, 4, 1024, 128),
+                                   (1, 2, 64, 2048), (1, 2, 2048, 64)])
+def test_fbm_lowpass_pow2_fast_path(L, shape):
+    """Power-of-two sizes take the register-blocked FFT; it must agree with the oracle and with the generic path."""
+    x = torch.from_numpy(gp.signed_input(shape, 14))
+    bands, pooled = run_lowpass(L, x, torch.float32)
+    ref = fr.fbm_lowpass(x.double()).float()
+    for k in range(3):
+        err = (bands[k] - ref[k]).abs().max().item()
+        assert err < 2e-5, (shape, k, err)
+    assert (pooled - x.mean(dim=(2, 3))).abs().max().item() < 1e-6
+    L.lib().sr_debug_force_generic_fft(1)
+    try:
+        bands_g, pooled_g = run_lowpass(L, x, torch.float32)
+    finally:
+        L.lib().sr_debug_force_generic_fft(0)
+    for k in range(3):
+        assert (bands[k] - bands_g[k]).abs().max().item() < 2e-5
+
+
+def test_fbm_lowpass_pow2_upsampled_bf16(L):
+    x = torch.from_numpy(gp.signed_input((2, 32, 64, 128), 15)).to(torch.bfloat16).float()
+    xu = F.interpolate(x, scale_factor=2, mode='nearest')
+    bands, pooled = run_lowpass(L, x, torch.bfloat16, ups=1)
+    ref = fr.fbm_lowpass(xu.double()).float()
+    for k in range(3):
+        assert (bands[k] - ref[k]).abs().max().item() < 4e-3
+    assert (pooled - xu.mean(dim=(2, 3))).abs().max().item() < 1e-5
+
+
 def test_fbm_lowpass_upsampled_and_bf16(L):
     x = torch.from_numpy(gp.signed_input((2, 8, 20, 24), 12))
     xu = F.interpolate(x, scale_factor=2, mode='nearest')
