@@ -66,8 +66,117 @@ __global__ __launch_bounds__(256) void fbm_gates_kernel(Concat in, int H, int W,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA version.  The 3x3 conv with 3 outputs is rewritten as a 1x1 product with 27 outputs,
+//     T[p][tap*3+k] = sum_c x[p][c] * w_k[c][tap],
+// followed by a 9-term shifted sum  logit_k[p] = sum_tap T[p + d(tap)][tap*3+k].  The product is
+// an M=32 (27 used) x N=pixels x K=Cin GEMM on v_mfma_f32_32x32x16_bf16: 9x fewer matrix ops than
+// the conv form, the activation operand goes global -> registers (each lane's fragment is 16
+// contiguous bytes of one pixel), and the kernel is bound by reading x once (+ tile halo).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short g_short8;
+typedef __attribute__((ext_vector_type(16))) float g_float16;
+
+constexpr int GMH = 8, GMW = 32;                 // interior tile
+constexpr int GPH = GMH + 2, GPW = GMW + 2;      // haloed tile: 340 pixel slots
+constexpr int GSLOTS = GPH * GPW;
+constexpr int GNT = (GSLOTS + 31) / 32;          // 11 N-tiles of 32 slots
+constexpr int GTROW = 27;                        // floats per slot in the T image (odd: conflict-free)
+
+__global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int H, int W, const float* __restrict__ w0,
+                                                      const float* __restrict__ w1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b0, const float* __restrict__ b1,
+                                                      const float* __restrict__ b2, float* __restrict__ gates) {
+    extern __shared__ __attribute__((aligned(16))) char glds[];
+    float* T = (float*)glds;                                  // [GNT*32][27]
+    char* A = glds + GNT * 32 * GTROW * sizeof(float);        // [32][cin*2 + 16] bf16 rows, padded
+    const int cin = in.ctot;
+    const int astride = cin * 2 + 16;
+    const int tilesx = (W + GMW - 1) / GMW;
+    const int b = blockIdx.y;
+    const int h0 = (blockIdx.x / tilesx) * GMH, w0p = (blockIdx.x % tilesx) * GMW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hk = lane >> 5;
+    const int Hs = H >> in.ups, Ws = W >> in.ups;
+    // stage the 27 x cin weight matrix as bf16 (rows 27..31 are zero)
+    const float* wk[3] = {w0, w1, w2};
+    for (int it = tid; it < 32 * cin; it += 256) {
+        const int c = it % cin, row = it / cin;
+        float v = 0.f;
+        if (row < 27) v = wk[row % 3][(long)c * 9 + row / 3];
+        *(bf16_t*)(A + row * astride + c * 2) = f32_to_bf16(v);
+    }
+    __syncthreads();
+    for (int nt = wave; nt < GNT; nt += 4) {
+        const int slot = nt * 32 + r;
+        const int py = slot / GPW, px = slot - py * GPW;
+        const int h = h0 + py - 1, w = w0p + px - 1;
+        const bool ok = slot < GSLOTS && h >= 0 && h < H && w >= 0 && w < W;
+        const long ps = ((long)b * Hs + (h >> in.ups)) * Ws + (w >> in.ups);
+        g_float16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        int kc = 0;
+        for (int s = 0; s < in.nseg; ++s) {
+            const View v = in.x[s];
+            const bf16_t* px0 = (const bf16_t*)v.p + ps * v.ld + v.c0 + hk * 8;
+            for (int cc = 0; cc < v.C; cc += 16, kc += 16) {
+                g_short8 bfrag = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) bfrag = *(const g_short8*)(px0 + cc);
+                const g_short8 afrag = *(const g_short8*)(A + r * astride + (kc + hk * 8) * 2);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+            }
+        }
+        // acc[i] = T[row = (i&3) + 8*(i>>2) + 4*hk][slot]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hk;
+            if (row < 27) T[slot * GTROW + row] = acc[i];
+        }
+    }
+    __syncthreads();
+    const int ty = tid / GMW, tx = tid % GMW;
+    const int h = h0 + ty, w = w0p + tx;
+    if (h < H && w < W) {
+        float lg[3] = {b0[0], b1[0], b2[0]};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* t = T + ((ty + tap / 3) * GPW + tx + tap % 3) * GTROW + tap * 3;
+            lg[0] += t[0];
+            lg[1] += t[1];
+            lg[2] += t[2];
+        }
+        float4 g;
+        g.x = 2.0f / (1.0f + expf(-lg[0]));
+        g.y = 2.0f / (1.0f + expf(-lg[1]));
+        g.z = 2.0f / (1.0f + expf(-lg[2]));
+        g.w = 0.f;
+        ((float4*)gates)[((long)b * H + h) * W + w] = g;
+    }
+}
+
+static bool gates_mfma_eligible(const Concat& in) {
+    if (in.ctot > 1024) return false;
+    for (int s = 0; s < in.nseg; ++s) {
+        const View& v = in.x[s];
+        if (v.C % 16 || v.c0 % 8 || v.ld % 8 || ((uintptr_t)v.p % 16)) return false;
+    }
+    return true;
+}
+
+int g_force_generic_gates = 0;  // test hook
+
 int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_layer_params& lp, float* gates,
                      hipStream_t st) {
+    if (dtype == SR_BF16 && !g_force_generic_gates && gates_mfma_eligible(in)) {
+        const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + 32ul * (in.ctot * 2 + 16);
+        SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fbm_gates_mfma<<<dim3(cdiv(H, GMH) * cdiv(W, GMW), B), 256, lds, st>>>(
+            in, H, W, lp.gate_w[0], lp.gate_w[1], lp.gate_w[2], lp.gate_b[0], lp.gate_b[1], lp.gate_b[2], gates);
+        SR_LAUNCH_CHECK();
+        return SR_OK;
+    }
     dim3 grid(cdiv(H, GT) * cdiv(W, GT), B);
     if (dtype == SR_F32)
         fbm_gates_kernel<float><<<grid, 256, 0, st>>>(in, H, W, lp.gate_w[0], lp.gate_w[1], lp.gate_w[2], lp.gate_b[0],
@@ -93,3 +202,5 @@ extern "C" int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in,
     for (int k = 0; k < 3; ++k) SR_REQUIRE(lp->gate_w[k] && lp->gate_b[k]);
     return fbm_gates_launch(dtype, B, H, W, c, *lp, gates, (hipStream_t)stream);
 }
+
+extern "C" void sr_debug_force_generic_gates(int on) { sr::g_force_generic_gates = on; }

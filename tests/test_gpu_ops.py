@@ -200,6 +200,43 @@ def test_fbm_gates(L):
     assert (got - ref).abs().max().item() < 1e-5
 
 
+def test_fbm_gates_bf16_mfma(L):
+    """bf16: the 27-output 1x1 product on MFMA + 9-tap combine, against fp64 on the same bf16-rounded operands"""
+    lib = L.lib()
+    keep = []
+    cin, cout = 160, 32
+    sd = gp.fdconv_params(cin, cout, 6)
+    lp, _ = make_lp(L, sd, cin, cout, torch.bfloat16, keep)
+    for (h, w, ups) in ((21, 37, 0), (8, 32, 0), (13, 20, 1)):
+        x = torch.from_numpy(gp.signed_input((2, cin, h, w), 16)).to(torch.bfloat16)
+        segs = [nhwc(x[:, :64].float(), torch.bfloat16)] + [nhwc(x[:, 64 + 32 * i:96 + 32 * i].float(), torch.bfloat16) for i in range(3)]
+        cc = L.Concat()
+        cc.nseg, cc.ups = 4, ups
+        for i, t_ in enumerate(segs):
+            cc.x[i] = L.view(t_)
+        H, W = h << ups, w << ups
+        t = {k: torch.from_numpy(v) for k, v in sd.items()}
+        gw = [t['FBM.freq_weight_conv_list.%d.weight' % i].to(torch.bfloat16).double() for i in range(3)]
+        gb = [t['FBM.freq_weight_conv_list.%d.bias' % i].double() for i in range(3)]
+        xr = x.double()
+        if ups:
+            xr = F.interpolate(xr, scale_factor=2, mode='nearest')
+        ref = fr.fbm_gates(xr, gw, gb).float()
+        outs = []
+        for force in (0, 1):
+            lib.sr_debug_force_generic_gates(force)
+            try:
+                gates = torch.full((2, H, W, 4), float('nan'), device='cuda:0')
+                L.check(lib.sr_fbm_gates(1, 2, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st(L)))
+                torch.cuda.synchronize()
+            finally:
+                lib.sr_debug_force_generic_gates(0)
+            outs.append(gates.cpu()[..., :3].permute(0, 3, 1, 2))
+        # MFMA path: weights rounded to bf16 (as in ref); generic path keeps fp32 weights -> looser
+        assert (outs[0] - ref).abs().max().item() < 2e-5, (h, w, ups)
+        assert (outs[1] - ref).abs().max().item() < 2e-2
+
+
 # ------------------------------------------------------------------------------------------ weights
 @pytest.mark.parametrize('cin,cout', gp.LAYER_SHAPES)
 def test_basis_and_weightgen(L, cin, cout):
