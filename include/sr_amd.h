@@ -11,8 +11,8 @@
  *
  * Conventions
  *   - every pointer is DEVICE memory on the current HIP device unless it says "host";
- *   - activations are NHWC ("pixel-major, channels innermost") in `dtype` (SR_F32 or SR_BF16):
- *     element (b,h,w,c) of a tensor view lives at ((b*H + h)*W + w)*ld + c0 + c;
+ *   - activations are NHWC ("pixel-major, channels innermost") or channel-blocked, in `dtype`
+ *     (SR_F32 or SR_BF16); see sr_view for the addressing;
  *   - no entry point allocates, frees or synchronises; work is enqueued on `stream`
  *     (a hipStream_t passed as void*); scratch memory is supplied by the caller;
  *     the exceptions are the *_create / *_destroy pairs which build small lookup tables;
@@ -39,13 +39,19 @@ extern "C" {
 
 #define SR_MAX_SEG 8 /* max tensors in a virtual channel concat */
 
-/* A view of `C` channels of an NHWC tensor whose pixels are `ld` elements apart. */
+/* A view of `C` channels of an activation tensor.  Element (b, pixel, c) with cc = c0 + c lives at
+ *     b*bs + (cc / 8)*cbs + pixel*ld + (cc % 8)            (in elements, pixel = h*W + w).
+ * NHWC is ld = channels of the underlying tensor, cbs = 8, bs = H*W*ld; leaving cbs = bs = 0 selects
+ * exactly that.  The channel-blocked layout [B][C/8][H][W][8] (what the executor uses for the 2x / 4x
+ * resolution tensors so that an image row of 8 channels is contiguous for the FFT passes) is
+ * ld = 8, cbs = 8*H*W, bs = C*H*W. */
 typedef struct {
     void* p;     /* base of the underlying tensor */
-    int32_t ld;  /* elements per pixel in the underlying tensor */
+    int32_t ld;  /* elements between consecutive pixels */
     int32_t c0;  /* first channel of the view */
     int32_t C;   /* channels in the view */
-    int32_t _pad;
+    int32_t cbs; /* elements between consecutive 8-channel blocks (0: NHWC) */
+    int64_t bs;  /* elements between consecutive samples (0: NHWC, H*W*ld) */
 } sr_view;
 
 /* The input of a conv: a virtual concat (torch.cat in RRDBNet's dense block) of up to

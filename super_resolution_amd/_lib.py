@@ -16,7 +16,8 @@ SR_MAX_SEG = 8
 
 
 class View(C.Structure):
-    _fields_ = [('p', C.c_void_p), ('ld', C.c_int32), ('c0', C.c_int32), ('C', C.c_int32), ('_pad', C.c_int32)]
+    _fields_ = [('p', C.c_void_p), ('ld', C.c_int32), ('c0', C.c_int32), ('C', C.c_int32), ('cbs', C.c_int32),
+                ('bs', C.c_int64)]
 
 
 class Concat(C.Structure):
@@ -120,11 +121,18 @@ def stream_ptr(device):
 def view(t, C_=None, c0=0):
     """sr_view over the last (channel) axis of a contiguous NHWC tensor."""
     ld = t.shape[-1]
-    return View(t.data_ptr(), ld, c0, ld - c0 if C_ is None else C_, 0)
+    return View(t.data_ptr(), ld, c0, ld - c0 if C_ is None else C_, 0, 0)
+
+
+def blocked_view(t):
+    """sr_view over a channel-blocked tensor of shape (B, C/8, H, W, 8)."""
+    B, cb, H, W, e = t.shape
+    assert e == 8 and t.is_contiguous()
+    return View(t.data_ptr(), 8, 0, cb * 8, 8 * H * W, cb * 8 * H * W)
 
 
 def null_view():
-    return View(None, 0, 0, 0, 0)
+    return View(None, 0, 0, 0, 0, 0)
 
 
 def ptr(t):

@@ -54,16 +54,36 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // device-side mirrors of the ABI structs (plain data, passed by value as kernel arguments)
 struct View {
     char* p;
-    int ld, c0, C;
+    int ld, c0, C, cbs;
+    long bs;
 };
-inline View to_view(const sr_view& v) { return View{(char*)v.p, v.ld, v.c0, v.C}; }
+// element offset of channel c of pixel `pix` (h*W + w of the view's own resolution) of sample b
+__host__ __device__ __forceinline__ long voff(const View& v, int b, long pix, int c) {
+    const int cc = v.c0 + c;
+    return (long)b * v.bs + (long)(cc >> 3) * v.cbs + pix * v.ld + (cc & 7);
+}
+// same without the sample term, in 32 bits (a sample is < 2^31 elements; checked on the host)
+__device__ __forceinline__ unsigned voff32(const View& v, unsigned pix, int c) {
+    const unsigned cc = (unsigned)(v.c0 + c);
+    return (cc >> 3) * (unsigned)v.cbs + pix * (unsigned)v.ld + (cc & 7u);
+}
+// npix: pixels per sample of the viewed tensor (fills the NHWC defaults)
+inline View to_view(const sr_view& v, long npix) {
+    return View{(char*)v.p, v.ld, v.c0, v.C, v.cbs ? v.cbs : 8, v.bs ? (long)v.bs : npix * v.ld};
+}
+inline View nhwc_view(void* p, int C, long npix) { return View{(char*)p, C, 0, C, 8, npix * C}; }
+inline View blocked_view(void* p, int C, long npix) { return View{(char*)p, 8, 0, C, (int)(8 * npix), npix * C}; }
+// 16-byte vector access to 8-channel groups / 8-byte access to 4-channel groups is legal
+inline bool view_vec_ok(const View& v, int mult) {
+    return v.p && ((uintptr_t)v.p % 16 == 0) && v.ld % mult == 0 && v.c0 % mult == 0 && v.cbs % 8 == 0 && v.bs % 8 == 0;
+}
 
 struct Concat {
     int nseg, bands, ups, ctot;
     View x[SR_MAX_SEG], l2[SR_MAX_SEG], l4[SR_MAX_SEG], l8[SR_MAX_SEG];
     int cstart[SR_MAX_SEG + 1];  // first concat channel of each segment
 };
-int to_concat(const sr_concat* in, Concat* out);  // validates; returns SR_OK / SR_ERR_ARG
+int to_concat(const sr_concat* in, long npix_x, long npix_bands, Concat* out);  // validates; SR_OK / SR_ERR_ARG
 
 struct Epilogue {
     const float* bias;
@@ -71,13 +91,13 @@ struct Epilogue {
     View r1, r2;
     float s1, s2;
 };
-inline Epilogue to_epilogue(const sr_epilogue* e) {
+inline Epilogue to_epilogue(const sr_epilogue* e, long npix) {
     Epilogue o{};
     if (e) {
         o.bias = e->bias;
         o.lrelu = e->lrelu;
-        o.r1 = to_view(e->r1);
-        o.r2 = to_view(e->r2);
+        o.r1 = to_view(e->r1, npix);
+        o.r2 = to_view(e->r2, npix);
         o.s1 = e->s1;
         o.s2 = e->s2;
     }

@@ -25,11 +25,11 @@ namespace sr {
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
 
 template <typename T>
-__device__ __forceinline__ float epilogue_one(float acc, int o, long pix, const Epilogue& ep) {
+__device__ __forceinline__ float epilogue_one(float acc, int o, int b, long pix, const Epilogue& ep) {
     float y = acc + (ep.bias ? ep.bias[o] : 0.f);
     if (ep.lrelu) y = lrelu02(y);
-    if (ep.r1.p) y = y * ep.s1 + Elem<T>::ld((const T*)ep.r1.p + pix * ep.r1.ld + ep.r1.c0 + o);
-    if (ep.r2.p) y = y * ep.s2 + Elem<T>::ld((const T*)ep.r2.p + pix * ep.r2.ld + ep.r2.c0 + o);
+    if (ep.r1.p) y = y * ep.s1 + Elem<T>::ld((const T*)ep.r1.p + voff(ep.r1, b, pix, o));
+    if (ep.r2.p) y = y * ep.s2 + Elem<T>::ld((const T*)ep.r2.p + voff(ep.r2, b, pix, o));
     return y;
 }
 
@@ -57,13 +57,6 @@ __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, 
     for (int o = 0; o < OT; ++o) acc[o] = 0.f;
     for (int s = 0; s < in.nseg; ++s) {
         const View vx = in.x[s];
-        const T* bx = (const T*)vx.p + (long)b * Hs * Ws * vx.ld + vx.c0;
-        const T *b2 = nullptr, *b4 = nullptr, *b8 = nullptr;
-        if (in.bands) {
-            b2 = (const T*)in.l2[s].p + (long)b * H * W * in.l2[s].ld + in.l2[s].c0;
-            b4 = (const T*)in.l4[s].p + (long)b * H * W * in.l4[s].ld + in.l4[s].c0;
-            b8 = (const T*)in.l8[s].p + (long)b * H * W * in.l8[s].ld + in.l8[s].c0;
-        }
         for (int cc = 0; cc < vx.C; cc += CCC) {
             const int nc = min(CCC, vx.C - cc);
             __syncthreads();
@@ -73,13 +66,13 @@ __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, 
                 const int h = ty0 + py - 1, w = tx0 + px - 1;
                 float val = 0.f;
                 if (h >= 0 && h < H && w >= 0 && w < W) {
-                    val = Elem<T>::ld(bx + ((long)(h >> in.ups) * Ws + (w >> in.ups)) * vx.ld + cc + c);
+                    val = Elem<T>::ld((const T*)vx.p + voff(vx, b, (long)(h >> in.ups) * Ws + (w >> in.ups), cc + c));
                     if (in.bands) {
                         const long p = (long)h * W + w;
                         const float4 g = ((const float4*)gates)[(long)b * H * W + p];
-                        const float v2 = Elem<T>::ld(b2 + p * in.l2[s].ld + cc + c);
-                        const float v4 = Elem<T>::ld(b4 + p * in.l4[s].ld + cc + c);
-                        const float v8 = Elem<T>::ld(b8 + p * in.l8[s].ld + cc + c);
+                        const float v2 = Elem<T>::ld((const T*)in.l2[s].p + voff(in.l2[s], b, p, cc + c));
+                        const float v4 = Elem<T>::ld((const T*)in.l4[s].p + voff(in.l4[s], b, p, cc + c));
+                        const float v8 = Elem<T>::ld((const T*)in.l8[s].p + voff(in.l8[s], b, p, cc + c));
                         val = g.x * val + (g.y - g.x) * v2 + (g.z - g.y) * v4 + (1.0f - g.z) * v8;
                     }
                 }
@@ -104,11 +97,11 @@ __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, 
     }
     const int h = ty0 + ty, w = tx0 + tx;
     if (h < H && w < W) {
-        const long pix = ((long)b * H + h) * W + w;
-        T* po = (T*)out.p + pix * out.ld + out.c0;
+        const long pix = (long)h * W + w;
 #pragma unroll
         for (int o = 0; o < OT; ++o)
-            if (o0 + o < cout) Elem<T>::st(po + o0 + o, epilogue_one<T>(acc[o], o0 + o, pix, ep));
+            if (o0 + o < cout)
+                Elem<T>::st((T*)out.p + voff(out, b, pix, o0 + o), epilogue_one<T>(acc[o], o0 + o, b, pix, ep));
     }
 }
 
@@ -161,24 +154,140 @@ __device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, f
     return r;
 }
 
-// MT = number of 32-wide output-channel tiles handled by the workgroup (1 or 2)
+// MT = number of 32-wide output-channel tiles handled by the workgroup (1 or 2).
+//
+// Producer / consumer workgroup of 8 waves, one per CU, two LDS stages:
+//   waves 4-7 (loaders)  stream the next 32-channel chunk global -> registers -> LDS (forming the FBM
+//                        modulated operand on the way), keeping tens of KiB of loads in flight per CU;
+//   waves 0-3 (MFMA)     run the 9 taps x 2 k-steps of the current chunk out of the other stage.
+// One barrier per chunk; the chunk time is max(HBM stream, MFMA), i.e. the kernel runs at whichever
+// roofline the layer is on (the banded FDConv operand is 4 tensors wide -> HBM).
+struct ChunkCursor {  // walks the virtual concat in 32-channel chunks
+    int s, cc, kc;
+};
+
 template <int MT, bool BANDS>
-__global__ __launch_bounds__(256) void conv3x3_mfma_bf16(Concat in, int H, int W, const float* __restrict__ gates,
+__device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor& cur, int b, int H, int W, int h0, int w0,
+                                            const float* __restrict__ gates, const bf16_t* __restrict__ wb, int cin,
+                                            int cout, int o_blk, char* lds_px, char* lds_w, int ltid) {
+    const View vx = in.x[cur.s];
+    const int Ws = W >> in.ups;
+    const bf16_t* xb = (const bf16_t*)vx.p + (long)b * vx.bs;
+    const bool blocked = vx.ld == 8;
+    // ---- haloed pixel tile: 612 pixels x 4 slots of 8 channels ---------------------------------------
+    // G items per thread are fetched before any is consumed: the loaders are the only waves with loads in
+    // flight on this CU, so each must keep ~20 x 16 B outstanding to cover the HBM latency.
+    constexpr int G = BANDS ? 4 : 10;
+    const View v2 = in.l2[cur.s], v4 = in.l4[cur.s], v8 = in.l8[cur.s];
+    const bf16_t* b2 = BANDS ? (const bf16_t*)v2.p + (long)b * v2.bs : nullptr;
+    const bf16_t* b4 = BANDS ? (const bf16_t*)v4.p + (long)b * v4.bs : nullptr;
+    const bf16_t* b8 = BANDS ? (const bf16_t*)v8.p + (long)b * v8.bs : nullptr;
+    const float4* gb = (const float4*)gates + (long)b * H * W;
+    for (int it0 = ltid; it0 < NPIX * 4; it0 += 256 * G) {
+        uint4 vx_[G], a2[G], a4[G], a8[G];
+        float4 gg[G];
+        int dst[G];
+        bool ok[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int it = it0 + g * 256;
+            int chunk, pi;
+            if (blocked) {  // a channel block's pixels are contiguous: pixels fastest
+                chunk = it / NPIX;
+                pi = it - chunk * NPIX;
+            } else {  // NHWC: the 4 slots of a pixel are contiguous
+                chunk = it & 3;
+                pi = it >> 2;
+            }
+            const int py = pi / PW, px = pi - py * PW;
+            const int h = h0 + py - 1, w = w0 + px - 1;
+            ok[g] = it < NPIX * 4 && h >= 0 && h < H && w >= 0 && w < W;
+            dst[g] = it < NPIX * 4 ? swz(pi, chunk) : -1;
+            // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards:
+            // a branch around a load makes hipcc drain the memory pipeline per element
+            const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+            const int ch = cur.cc + (chunk & 3) * 8;
+            const unsigned ps = (unsigned)(hc >> in.ups) * Ws + (wc >> in.ups);
+            vx_[g] = *(const uint4*)(xb + voff32(vx, ps, ch));
+            if (BANDS) {
+                const unsigned p = (unsigned)hc * W + wc;
+                a2[g] = *(const uint4*)(b2 + voff32(v2, p, ch));
+                a4[g] = *(const uint4*)(b4 + voff32(v4, p, ch));
+                a8[g] = *(const uint4*)(b8 + voff32(v8, p, ch));
+                gg[g] = gb[p];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            uint4 v = vx_[g];
+            if (BANDS) v = modulate8(v, a2[g], a4[g], a8[g], gg[g].x, gg[g].y - gg[g].x, gg[g].z - gg[g].y, 1.0f - gg[g].z);
+            if (!ok[g]) v = make_uint4(0u, 0u, 0u, 0u);
+            if (dst[g] >= 0) *(uint4*)(lds_px + dst[g]) = v;
+        }
+    }
+    // ---- weight slab: rows (tap, o) x 32 channels (L2-resident) -------------------------------------------
+    constexpr int WITEMS = 9 * MT * 32 * 4;
+    constexpr int WG = (WITEMS + 255) / 256;
+    uint4 wv[WG];
+#pragma unroll
+    for (int g = 0; g < WG; ++g) {
+        const int it = ltid + g * 256;
+        const int chunk = it & 3, row = it >> 2;
+        const int tap = row / (MT * 32), o = row - tap * (MT * 32);
+        const int tapc = min(tap, 8), oc = min(o_blk + o, cout - 1);
+        wv[g] = *(const uint4*)(wb + ((long)tapc * cout + oc) * cin + cur.kc + chunk * 8);
+        if (o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int g = 0; g < WG; ++g) {
+        const int it = ltid + g * 256;
+        if (it < WITEMS) *(uint4*)(lds_w + swz(it >> 2, it & 3)) = wv[g];
+    }
+}
+
+__device__ __forceinline__ bool advance(const Concat& in, ChunkCursor& cur) {
+    cur.cc += 32;
+    cur.kc += 32;
+    if (cur.cc >= in.x[cur.s].C) {
+        cur.cc = 0;
+        cur.s += 1;
+    }
+    return cur.s < in.nseg;
+}
+
+template <int MT, bool BANDS>
+__global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, int cin,
                                                          int cout, Epilogue ep, View out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* lds_px = lds;                 // NPIX rows x 64 B
-    char* lds_w = lds + NPIX * 64;      // 9*MT*32 rows x 64 B
+    constexpr int STAGE = NPIX * 64 + 9 * MT * 32 * 64;  // pixel tile + weight slab
     const int tilesx = (W + MTW - 1) / MTW;
     const int b = blockIdx.y;
     const int o_blk = blockIdx.z * (MT * 32);
     const int h0 = (blockIdx.x / tilesx) * MTH, w0 = (blockIdx.x % tilesx) * MTW;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
     const int r = lane & 31, hk = lane >> 5;
-    const int Hs = H >> in.ups, Ws = W >> in.ups;
     const bf16_t* wb = wts + (long)b * w_bstride;
 
+    const int nchunks = cin / 32;
+    constexpr int STAGE_PX = NPIX * 64;
+    if (loader) {
+        // ---- producer waves: never touch the accumulators (separate register budget) --------------
+        ChunkCursor cur{0, 0, 0};
+        stage_chunk<MT, BANDS>(in, cur, b, H, W, h0, w0, gates, wb, cin, cout, o_blk, lds, lds + STAGE_PX, tid - 256);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (advance(in, cur)) {
+                char* nxt = lds + ((c + 1) & 1) * STAGE;
+                stage_chunk<MT, BANDS>(in, cur, b, H, W, h0, w0, gates, wb, cin, cout, o_blk, nxt, nxt + STAGE_PX, tid - 256);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     float16v acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -186,62 +295,30 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_bf16(Concat in, int H, int W
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-
-    int kc = 0;  // first concat channel of the current 32-channel chunk
-    for (int s = 0; s < in.nseg; ++s) {
-        const View vx = in.x[s];
-        for (int cc = 0; cc < vx.C; cc += 32, kc += 32) {
-            __syncthreads();
-            // ---- stage the haloed pixel tile: 612 pixels x 4 slots of 8 channels -------------------
-            for (int it = tid; it < NPIX * 4; it += 256) {
-                const int chunk = it & 3, pi = it >> 2;
-                const int py = pi / PW, px = pi - py * PW;
-                const int h = h0 + py - 1, w = w0 + px - 1;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (h >= 0 && h < H && w >= 0 && w < W) {
-                    const long ps = ((long)b * Hs + (h >> in.ups)) * Ws + (w >> in.ups);
-                    v = *(const uint4*)((const bf16_t*)vx.p + ps * vx.ld + vx.c0 + cc + chunk * 8);
-                    if (BANDS) {
-                        const long p = ((long)b * H + h) * W + w;
-                        const float4 g = ((const float4*)gates)[p];
-                        const uint4 a2 = *(const uint4*)((const bf16_t*)in.l2[s].p + p * in.l2[s].ld + in.l2[s].c0 + cc + chunk * 8);
-                        const uint4 a4 = *(const uint4*)((const bf16_t*)in.l4[s].p + p * in.l4[s].ld + in.l4[s].c0 + cc + chunk * 8);
-                        const uint4 a8 = *(const uint4*)((const bf16_t*)in.l8[s].p + p * in.l8[s].ld + in.l8[s].c0 + cc + chunk * 8);
-                        v = modulate8(v, a2, a4, a8, g.x, g.y - g.x, g.z - g.y, 1.0f - g.z);
-                    }
-                }
-                *(uint4*)(lds_px + swz(pi, chunk)) = v;
-            }
-            // ---- stage the weight slab: rows (tap, o) x 32 channels ---------------------------------
-            for (int it = tid; it < 9 * MT * 32 * 4; it += 256) {
-                const int chunk = it & 3, row = it >> 2;
-                const int tap = row / (MT * 32), o = row - tap * (MT * 32);
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (o_blk + o < cout) v = *(const uint4*)(wb + ((long)tap * cout + o_blk + o) * cin + kc + chunk * 8);
-                *(uint4*)(lds_w + swz(row, chunk)) = v;
-            }
-            __syncthreads();
-            // ---- 9 taps x 2 k-steps of 16 channels --------------------------------------------------
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const char* cur_px = lds + (c & 1) * STAGE;
+        const char* cur_w = cur_px + STAGE_PX;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap % 3;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int chunk = kk * 2 + hk;
-                    short8 af[MT];
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = kk * 2 + hk;
+                short8 af[MT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) af[m] = *(const short8*)(lds_w + swz(tap * (MT * 32) + m * 32 + r, chunk));
+                for (int m = 0; m < MT; ++m) af[m] = *(const short8*)(cur_w + swz(tap * (MT * 32) + m * 32 + r, chunk));
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const int pi = (wave * 4 + n + dy) * PW + r + dx;
-                        const short8 bf = *(const short8*)(lds_px + swz(pi, chunk));
+                for (int n = 0; n < 4; ++n) {
+                    const int pi = (wave * 4 + n + dy) * PW + r + dx;
+                    const short8 bf = *(const short8*)(cur_px + swz(pi, chunk));
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
-                    }
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
                 }
             }
         }
+        __syncthreads();
     }
     // ---- epilogue: lane holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each tile ----
     const int w = w0 + r;
@@ -249,7 +326,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_bf16(Concat in, int H, int W
     for (int n = 0; n < 4; ++n) {
         const int h = h0 + wave * 4 + n;
         if (h >= H || w >= W) continue;
-        const long pix = ((long)b * H + h) * W + w;
+        const long pix = (long)h * W + w;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -264,14 +341,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_bf16(Concat in, int H, int W
                     for (int j = 0; j < 4; ++j) y[j] = lrelu02(y[j]);
                 }
                 if (ep.r1.p) {
-                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r1.p + pix * ep.r1.ld + ep.r1.c0 + o);
+                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r1.p + voff(ep.r1, b, pix, o));
                     y[0] = y[0] * ep.s1 + lo_f(rr.x);
                     y[1] = y[1] * ep.s1 + hi_f(rr.x);
                     y[2] = y[2] * ep.s1 + lo_f(rr.y);
                     y[3] = y[3] * ep.s1 + hi_f(rr.y);
                 }
                 if (ep.r2.p) {
-                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r2.p + pix * ep.r2.ld + ep.r2.c0 + o);
+                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r2.p + voff(ep.r2, b, pix, o));
                     y[0] = y[0] * ep.s2 + lo_f(rr.x);
                     y[1] = y[1] * ep.s2 + hi_f(rr.x);
                     y[2] = y[2] * ep.s2 + lo_f(rr.y);
@@ -280,14 +357,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_bf16(Concat in, int H, int W
                 uint2 st;
                 st.x = pack2(y[0], y[1]);
                 st.y = pack2(y[2], y[3]);
-                *(uint2*)((bf16_t*)out.p + pix * out.ld + out.c0 + o) = st;
+                *(uint2*)((bf16_t*)out.p + voff(out, b, pix, o)) = st;
             }
         }
     }
-}
-
-static bool view_vec_ok(const View& v, int mult) {
-    return v.p && ((uintptr_t)v.p % 16 == 0) && v.ld % mult == 0 && v.c0 % mult == 0;
 }
 
 static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const View& out, const void* wts,
@@ -295,9 +368,12 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
     if (cout % 32 != 0) return false;
     if ((uintptr_t)wts % 16 != 0 || wbs % 8 != 0) return false;
     for (int s = 0; s < in.nseg; ++s) {
-        if (in.x[s].C % 32 != 0 || !view_vec_ok(in.x[s], 8)) return false;
-        if (in.bands && (!view_vec_ok(in.l2[s], 8) || !view_vec_ok(in.l4[s], 8) || !view_vec_ok(in.l8[s], 8)))
-            return false;
+        if (in.x[s].C % 32 != 0 || !view_vec_ok(in.x[s], 8) || in.x[s].bs >= (1L << 31)) return false;
+        if (in.bands) {
+            const View* bv[3] = {&in.l2[s], &in.l4[s], &in.l8[s]};
+            for (const View* v : bv)
+                if (!view_vec_ok(*v, 8) || v->bs >= (1L << 31)) return false;
+        }
     }
     if (!view_vec_ok(out, 4)) return false;
     if (ep.r1.p && !view_vec_ok(ep.r1, 4)) return false;
@@ -308,7 +384,7 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
 template <int MT, bool BANDS>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
-    const size_t ldsb = (size_t)NPIX * 64 + 9ul * MT * 32 * 64;
+    const size_t ldsb = 2 * ((size_t)NPIX * 64 + 9ul * MT * 32 * 64);
     static bool attr_set = false;
     if (!attr_set) {
         SR_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_bf16<MT, BANDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -316,7 +392,7 @@ static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates
         attr_set = true;
     }
     dim3 grid(cdiv(H, MTH) * cdiv(W, MTW), B, cdiv(cout, MT * 32));
-    conv3x3_mfma_bf16<MT, BANDS><<<grid, 256, ldsb, st>>>(in, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out);
+    conv3x3_mfma_bf16<MT, BANDS><<<grid, 512, ldsb, st>>>(in, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -344,16 +420,17 @@ extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, c
                           long w_bstride, int cout, const sr_epilogue* ep, sr_view out, void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && in && weights && cout > 0 && out.p);
     SR_REQUIRE(B <= 65535 && w_bstride >= 0);
+    SR_REQUIRE(!in->ups || (H % 2 == 0 && W % 2 == 0));
+    const long npix = (long)H * W;
     Concat c;
-    int rc = to_concat(in, &c);
+    int rc = to_concat(in, in->ups ? npix / 4 : npix, npix, &c);
     if (rc != SR_OK) return rc;
     SR_REQUIRE(!c.bands || gates);
-    SR_REQUIRE(!c.ups || (H % 2 == 0 && W % 2 == 0));
-    SR_REQUIRE(out.C == cout && out.c0 >= 0 && out.c0 + cout <= out.ld);
-    Epilogue e = to_epilogue(ep);
-    SR_REQUIRE(!e.r1.p || (e.r1.C == cout && e.r1.c0 + cout <= e.r1.ld));
-    SR_REQUIRE(!e.r2.p || (e.r2.C == cout && e.r2.c0 + cout <= e.r2.ld));
-    return conv3x3_launch(dtype, B, H, W, c, gates, weights, w_bstride, cout, e, to_view(out), (hipStream_t)stream);
+    SR_REQUIRE(out.C == cout && out.c0 >= 0 && (out.cbs || out.c0 + cout <= out.ld));
+    Epilogue e = to_epilogue(ep, npix);
+    SR_REQUIRE(!e.r1.p || e.r1.C == cout);
+    SR_REQUIRE(!e.r2.p || e.r2.C == cout);
+    return conv3x3_launch(dtype, B, H, W, c, gates, weights, w_bstride, cout, e, to_view(out, npix), (hipStream_t)stream);
 }
 
 // test hook (not part of the product API): 1 routes bf16 convs through the VALU kernel

@@ -150,14 +150,14 @@ __global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int 
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int p0 = blockIdx.y * P;
     const int Hs = H >> ups, Ws = W >> ups;
-    const T* row = (const T*)x.p + ((long)b * Hs + (h >> ups)) * Ws * x.ld + x.c0;
+    (void)Hs;
     for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
         const int p = it % P, w = it / P;
         const int c = 2 * (p0 + p);
-        const T* px = row + (long)(w >> ups) * x.ld + c;
+        const long pix = (long)(h >> ups) * Ws + (w >> ups);
         float2 v = make_float2(0.f, 0.f);
-        if (c < C) v.x = Elem<T>::ld(px);
-        if (c + 1 < C) v.y = Elem<T>::ld(px + 1);
+        if (c < C) v.x = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c));
+        if (c + 1 < C) v.y = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c + 1));
         bufA[it] = v;
     }
     __syncthreads();
@@ -239,14 +239,13 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
         }
         __syncthreads();
         const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, tw, nullptr);
-        T* row = (T*)outs[k].p + ((long)b * H + h) * W * outs[k].ld + outs[k].c0;
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
             const int p = it % P, w = it / P;
             const int c = 2 * (p0 + p);
             const float2 v = res[it];
-            T* px = row + (long)w * outs[k].ld + c;
-            if (c < C) Elem<T>::st(px, v.x * norm);
-            if (c + 1 < C) Elem<T>::st(px + 1, v.y * norm);
+            const long pix = (long)h * W + w;
+            if (c < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c), v.x * norm);
+            if (c + 1 < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c + 1), v.y * norm);
         }
         __syncthreads();
     }
@@ -420,7 +419,7 @@ extern "C" void sr_fbm_plan_destroy(sr_fbm_plan* pl) {
 
 extern "C" size_t sr_fbm_workspace_bytes(const sr_fbm_plan* pl, int B, int C) {
     if (!pl || B < 1 || C < 1) return 0;
-    const size_t PT = (C + 1) / 2;
+    const size_t PT = align_up((size_t)(C + 1) / 2, 16);  // the pow2 path stores whole pair groups
     const size_t n = (size_t)pl->n[0] * 2 + pl->n[1] + pl->n[2];
     return align_up((size_t)B * pl->H * n * PT * sizeof(float2), 256);
 }
@@ -429,9 +428,10 @@ extern "C" int sr_fbm_lowpass(const sr_fbm_plan* pl, int dtype, int B, sr_view x
                               sr_view l8, float* pooled, int pooled_ld, void* ws, size_t ws_bytes, void* stream) {
     SR_REQUIRE(pl && dtype_ok(dtype) && B > 0 && x.p && l2.p && l4.p && l8.p && ws);
     SR_REQUIRE(x.C > 0 && l2.C == x.C && l4.C == x.C && l8.C == x.C);
-    SR_REQUIRE(x.c0 >= 0 && x.c0 + x.C <= x.ld && l2.c0 + x.C <= l2.ld && l4.c0 + x.C <= l4.ld && l8.c0 + x.C <= l8.ld);
+    SR_REQUIRE(x.c0 >= 0 && l2.c0 >= 0 && l4.c0 >= 0 && l8.c0 >= 0);
     SR_REQUIRE(ups == 0 || (pl->H % 2 == 0 && pl->W % 2 == 0));
     SR_REQUIRE(!pooled || pooled_ld >= x.C);
-    return fbm_lowpass_launch(pl, dtype, B, to_view(x), ups ? 1 : 0, to_view(l2), to_view(l4), to_view(l8), pooled,
-                              pooled_ld, ws, ws_bytes, (hipStream_t)stream);
+    const long npix = (long)pl->H * pl->W;
+    return fbm_lowpass_launch(pl, dtype, B, to_view(x, ups ? npix / 4 : npix), ups ? 1 : 0, to_view(l2, npix),
+                              to_view(l4, npix), to_view(l8, npix), pooled, pooled_ld, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -18,7 +18,7 @@
 namespace sr {
 namespace fast {
 
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -83,12 +83,32 @@ struct Dft<8, INV> {
 constexpr int pick_radix(int m) { return (m % 8 == 0 && m != 16) ? 8 : (m % 4 == 0 ? 4 : 2); }
 constexpr int first_radix(int n) { return pick_radix(n); }
 
-// One Stockham pass.  load(idx, p) / store(idx, p, v) address point idx of signal p.
-template <int N, int P, int R, int NS, bool INV, bool LOAD_LDS, bool STORE_LDS, typename LoadF, typename StoreF>
+// Work item i of a pass with NBJ butterflies per signal -> (signal p, butterfly j).
+//   BLK = false (NHWC, channels contiguous per pixel): p fastest, so a wave touches P*8 contiguous bytes.
+//   BLK = true  (channel-blocked [C/8][H][W][8]): the 4 pairs of a channel block fastest, then the
+//               butterfly, so a wave's global accesses run along the image row of one channel block.
+template <int P, int NBJ, bool BLK>
+__device__ __forceinline__ void item_to_pj(int i, int& p, int& j) {
+    if (BLK) {
+        p = (i & 3) + 4 * (i / (4 * NBJ));
+        j = (i >> 2) % NBJ;
+    } else {
+        p = i % P;
+        j = i / P;
+    }
+}
+// LDS image of the N x P complex working set, matching the lane order above (conflict-free ds access)
+template <int N, int P, bool BLK>
+__device__ __forceinline__ int lds_idx(int idx, int p) {
+    return BLK ? (((p >> 2) * N + idx) * 4 + (p & 3)) : (idx * P + p);
+}
+
+// One Stockham pass.  load(idx, p, q, t) / store(idx, p, v) address point idx of signal p.
+template <int N, int P, int R, int NS, bool INV, bool BLK, bool LOAD_LDS, bool STORE_LDS, typename LoadF, typename StoreF>
 __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load, StoreF store) {
-    constexpr int NB = N / R * P;
-    constexpr int IT = (NB + THREADS - 1) / THREADS;
     constexpr int NR = N / R;
+    constexpr int NB = NR * P;
+    constexpr int IT = (NB + THREADS - 1) / THREADS;
     constexpr int TSTEP = N / (NS * R);
     float2 v[IT][R];
     if (LOAD_LDS) __syncthreads();
@@ -96,7 +116,8 @@ __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load,
     for (int q = 0; q < IT; ++q) {
         const int i = threadIdx.x + q * THREADS;
         if (NB % THREADS != 0 && i >= NB) continue;
-        const int p = i % P, j = i / P;
+        int p, j;
+        item_to_pj<P, NR, BLK>(i, p, j);
         const int k = j % NS;
 #pragma unroll
         for (int t = 0; t < R; ++t) v[q][t] = load(j + t * NR, p, q, t);
@@ -115,7 +136,8 @@ __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load,
     for (int q = 0; q < IT; ++q) {
         const int i = threadIdx.x + q * THREADS;
         if (NB % THREADS != 0 && i >= NB) continue;
-        const int p = i % P, j = i / P;
+        int p, j;
+        item_to_pj<P, NR, BLK>(i, p, j);
         const int k = j % NS;
         const int base = (j / NS) * NS * R + k;
 #pragma unroll
@@ -126,22 +148,22 @@ __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load,
 // All passes of a length-N transform: first pass loads through `lf`, last pass stores through `sl`,
 // everything in between lives in `buf` (N x P complex, in place).
 // LAST_LDS: the caller's `sl` writes into `buf` (needs the read/write barrier).
-template <int N, int P, bool INV, int NS, bool LAST_LDS, typename LoadFirst, typename StoreLast>
+template <int N, int P, bool INV, bool BLK, int NS, bool LAST_LDS, typename LoadFirst, typename StoreLast>
 __device__ __forceinline__ void fft(float2* __restrict__ buf, const float2* __restrict__ twl, LoadFirst lf, StoreLast sl) {
     constexpr int M = N / NS;
     constexpr int R = pick_radix(M);
     constexpr bool first = (NS == 1), last = (M == R);
-    auto lds_load = [&](int idx, int p, int, int) { return buf[idx * P + p]; };
-    auto lds_store = [&](int idx, int p, float2 v) { buf[idx * P + p] = v; };
+    auto lds_load = [&](int idx, int p, int, int) { return buf[lds_idx<N, P, BLK>(idx, p)]; };
+    auto lds_store = [&](int idx, int p, float2 v) { buf[lds_idx<N, P, BLK>(idx, p)] = v; };
     if constexpr (first && last)
-        pass<N, P, R, NS, INV, false, true>(twl, lf, sl);
+        pass<N, P, R, NS, INV, BLK, false, true>(twl, lf, sl);
     else if constexpr (first)
-        pass<N, P, R, NS, INV, false, true>(twl, lf, lds_store);
+        pass<N, P, R, NS, INV, BLK, false, true>(twl, lf, lds_store);
     else if constexpr (last)
-        pass<N, P, R, NS, INV, true, LAST_LDS>(twl, lds_load, sl);
+        pass<N, P, R, NS, INV, BLK, true, LAST_LDS>(twl, lds_load, sl);
     else
-        pass<N, P, R, NS, INV, true, true>(twl, lds_load, lds_store);
-    if constexpr (!last) fft<N, P, INV, NS * R, LAST_LDS>(buf, twl, lf, sl);
+        pass<N, P, R, NS, INV, BLK, true, true>(twl, lds_load, lds_store);
+    if constexpr (!last) fft<N, P, INV, BLK, NS * R, LAST_LDS>(buf, twl, lf, sl);
 }
 
 extern __shared__ __attribute__((aligned(16))) char smem_fast[];
@@ -177,35 +199,47 @@ __device__ __forceinline__ int kept_pos(int c, int a) {
     return c < a ? c : (c > N - a ? c - (N - (2 * a - 1)) : -1);
 }
 
+// Intermediates are stored per group of Q pairs: T1[b][pg][pos][h][Q], Y_k[b][pg][h][pos][Q].
+struct Inter {
+    int Q, NPG, QL;  // pairs per group (power of two), groups per sample, log2(Q)
+};
+// offsets inside one sample (32-bit: a sample's intermediates are < 2^31 elements, checked on the host)
+__device__ __forceinline__ unsigned t1_off(const Inter& it, int gp, int pos, int h, int n2, int H) {
+    return ((((unsigned)(gp >> it.QL) * n2 + pos) * H + h) << it.QL) + (gp & (it.Q - 1));
+}
+__device__ __forceinline__ unsigned y_off(const Inter& it, int gp, int h, int pos, int nk, int H) {
+    return ((((unsigned)(gp >> it.QL) * H + h) * nk + pos) << it.QL) + (gp & (it.Q - 1));
+}
+
 // ---- rows forward -------------------------------------------------------------------------
-template <typename T, int N, int P>
-__global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int PT, const float2* __restrict__ tw,
-                                                    int a2, float2* __restrict__ t1) {
+template <typename T, int N, int P, bool BLK>
+__global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int PT, Inter im,
+                                                    const float2* __restrict__ tw, int a2, float2* __restrict__ t1) {
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int p0 = blockIdx.y * P;
     const int n2 = 2 * a2 - 1;
-    const int Ws = N >> ups;
-    const T* row = (const T*)x.p + ((long)b * (H >> ups) + (h >> ups)) * Ws * x.ld + x.c0 + 2 * p0;
+    const unsigned rowpix = (unsigned)(h >> ups) * (N >> ups);
+    const T* xb = (const T*)x.p + (long)b * x.bs;
+    float2* t1b = t1 + ((long)b * im.NPG * n2 * H << im.QL);
     auto lf = [&](int idx, int p, int, int) {
-        return (p0 + p < PT) ? Pair<T>::ld(row + (long)(idx >> ups) * x.ld + 2 * p) : make_float2(0.f, 0.f);
+        return (p0 + p < PT) ? Pair<T>::ld(xb + voff32(x, rowpix + (idx >> ups), 2 * (p0 + p))) : make_float2(0.f, 0.f);
     };
-    float2* out = t1 + ((long)b * n2 * H + h) * PT + p0;
     auto sl = [&](int idx, int p, float2 v) {
         const int pos = kept_pos<N>(idx, a2);
-        if (pos >= 0 && p0 + p < PT) out[(long)pos * H * PT + p] = v;
+        if (pos >= 0 && p0 + p < PT) t1b[t1_off(im, p0 + p, pos, h, n2, H)] = v;
     };
-    fft<N, P, false, 1, false>(buf, twl, lf, sl);
+    fft<N, P, false, BLK, 1, false>(buf, twl, lf, sl);
 }
 
 // ---- columns: forward, mask, inverse x3 ------------------------------------------------------
-template <int N, int P>
-__global__ __launch_bounds__(THREADS) void cols(int W, int PT, const float2* __restrict__ tw, int a2, int a4, int a8,
-                                                const float* __restrict__ rowmask, const float2* __restrict__ t1,
-                                                float2* __restrict__ y2, float2* __restrict__ y4,
-                                                float2* __restrict__ y8, float* __restrict__ pooled, int pooled_ld,
-                                                int C) {
+template <int N, int P, bool BLK>
+__global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
+                                                int a8, const float* __restrict__ rowmask,
+                                                const float2* __restrict__ t1, float2* __restrict__ y2,
+                                                float2* __restrict__ y4, float2* __restrict__ y8,
+                                                float* __restrict__ pooled, int pooled_ld, int C) {
     constexpr int H = N;
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
@@ -213,30 +247,35 @@ __global__ __launch_bounds__(THREADS) void cols(int W, int PT, const float2* __r
     const int b = blockIdx.x / n2, idx = blockIdx.x % n2;
     const int p0 = blockIdx.y * P;
     const int col = idx < a2 ? idx : idx + (W - n2);  // full-spectrum column of this block
-    const float2* src = t1 + ((long)b * n2 + idx) * H * PT + p0;
-    auto lf = [&](int h, int p, int, int) { return (p0 + p < PT) ? src[(long)h * PT + p] : make_float2(0.f, 0.f); };
-    auto s_lds = [&](int r, int p, float2 v) { buf[r * P + p] = v; };
+    const float2* t1b = t1 + ((long)b * im.NPG * n2 * H << im.QL);
+    auto lf = [&](int h, int p, int, int) {
+        return (p0 + p < PT) ? t1b[t1_off(im, p0 + p, idx, h, n2, H)] : make_float2(0.f, 0.f);
+    };
+    auto s_lds = [&](int r, int p, float2 v) { buf[lds_idx<N, P, BLK>(r, p)] = v; };
     // forward: the last pass stores back into LDS
-    fft<N, P, false, 1, true>(buf, twl, lf, s_lds);
+    fft<N, P, false, BLK, 1, true>(buf, twl, lf, s_lds);
     __syncthreads();
     if (pooled && idx == 0 && threadIdx.x < P && p0 + threadIdx.x < PT) {
         const int c = 2 * (p0 + threadIdx.x);
         const float inv = 1.0f / ((float)H * (float)W);
-        if (c < C) pooled[(long)b * pooled_ld + c] = buf[threadIdx.x].x * inv;
-        if (c + 1 < C) pooled[(long)b * pooled_ld + c + 1] = buf[threadIdx.x].y * inv;
+        const float2 dc = buf[lds_idx<N, P, BLK>(0, threadIdx.x)];
+        if (c < C) pooled[(long)b * pooled_ld + c] = dc.x * inv;
+        if (c + 1 < C) pooled[(long)b * pooled_ld + c + 1] = dc.y * inv;
     }
     // keep this thread's first-pass operands of the spectrum in registers
     constexpr int R0 = first_radix(N);
-    constexpr int NB = N / R0 * P;
+    constexpr int NR0 = N / R0;
+    constexpr int NB = NR0 * P;
     constexpr int IT = (NB + THREADS - 1) / THREADS;
     float2 sreg[IT][R0];
 #pragma unroll
     for (int q = 0; q < IT; ++q) {
         const int i = threadIdx.x + q * THREADS;
-        const int p = i % P, j = i / P;
+        int p, j;
+        item_to_pj<P, NR0, BLK>(i, p, j);
 #pragma unroll
         for (int t = 0; t < R0; ++t)
-            sreg[q][t] = (NB % THREADS == 0 || i < NB) ? buf[(j + t * (N / R0)) * P + p] : make_float2(0.f, 0.f);
+            sreg[q][t] = (NB % THREADS == 0 || i < NB) ? buf[lds_idx<N, P, BLK>(j + t * NR0, p)] : make_float2(0.f, 0.f);
     }
     const int variant = (col == 0 || 2 * col == W) ? 2 : (2 * col < W ? 0 : 1);
     const int ak[3] = {a2, a4, a8};
@@ -253,17 +292,17 @@ __global__ __launch_bounds__(THREADS) void cols(int W, int PT, const float2* __r
             const float m = rm[r];
             return make_float2(sreg[q][t].x * m, sreg[q][t].y * m);
         };
-        float2* y = ys[k] + ((long)b * H * nk + pos) * PT + p0;
+        float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
         auto sl = [&](int h, int p, float2 v) {
-            if (p0 + p < PT) y[(long)h * nk * PT + p] = v;
+            if (p0 + p < PT) y[y_off(im, p0 + p, h, pos, nk, H)] = v;
         };
-        fft<N, P, true, 1, false>(buf, twl, lm, sl);
+        fft<N, P, true, BLK, 1, false>(buf, twl, lm, sl);
     }
 }
 
 // ---- rows inverse -------------------------------------------------------------------------
-template <typename T, int N, int P>
-__global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, int H, int PT,
+template <typename T, int N, int P, bool BLK>
+__global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, int a4, int a8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
                                                     const float2* __restrict__ y8) {
@@ -275,57 +314,61 @@ __global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, i
     const int ak[3] = {a2, a4, a8};
     const float2* ys[3] = {y2, y4, y8};
     const View outs[3] = {l2, l4, l8};
+    const unsigned rowpix = (unsigned)h * N;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int a = ak[k];
         const int nk = 2 * a - 1;
-        const float2* yr = ys[k] + ((long)b * H + h) * nk * PT + p0;
+        const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
         auto lf = [&](int c, int p, int, int) {
             const int pos = kept_pos<N>(c, a);
-            return (pos >= 0 && p0 + p < PT) ? yr[(long)pos * PT + p] : make_float2(0.f, 0.f);
+            return (pos >= 0 && p0 + p < PT) ? y[y_off(im, p0 + p, h, pos, nk, H)] : make_float2(0.f, 0.f);
         };
-        T* row = (T*)outs[k].p + ((long)b * H + h) * N * outs[k].ld + outs[k].c0 + 2 * p0;
-        const int ld = outs[k].ld;
+        const View o = outs[k];
+        T* ob = (T*)o.p + (long)b * o.bs;
         auto sl = [&](int w, int p, float2 v) {
-            if (p0 + p < PT) Pair<T>::st(row + (long)w * ld + 2 * p, make_float2(v.x * norm, v.y * norm));
+            if (p0 + p < PT) Pair<T>::st(ob + voff32(o, rowpix + w, 2 * (p0 + p)), make_float2(v.x * norm, v.y * norm));
         };
-        fft<N, P, true, 1, false>(buf, twl, lf, sl);
+        fft<N, P, true, BLK, 1, false>(buf, twl, lf, sl);
     }
 }
 
 // ---- host dispatch ---------------------------------------------------------------------------
 constexpr int pairs_for(int n) { return n <= 512 ? 16 : (n == 1024 ? 8 : 4); }
+inline int pairs_for_rt(int n) { return pairs_for(n); }
 
-template <typename T, int N>
-static int launch_rows_fwd(View x, int ups, int B, int H, int PT, const sr_fbm_plan* pl, float2* t1, hipStream_t st) {
+template <typename T, int N, bool BLK>
+static int launch_rows_fwd(View x, int ups, int B, int H, int PT, Inter im, const sr_fbm_plan* pl, float2* t1,
+                           hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
-    SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rows_fwd<T, N, P><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, pl->tw_w, pl->half[0], t1);
+    SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rows_fwd<T, N, P, BLK><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, im, pl->tw_w, pl->half[0], t1);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
 
-template <typename T, int N>
-static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, const sr_fbm_plan* pl, const float2* y2,
-                           const float2* y4, const float2* y8, hipStream_t st) {
+template <typename T, int N, bool BLK>
+static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inter im, const sr_fbm_plan* pl,
+                           const float2* y2, const float2* y4, const float2* y8, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
-    SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rows_inv<T, N, P><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, pl->tw_w, pl->half[0],
-                                                                   pl->half[1], pl->half[2], y2, y4, y8);
+    SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rows_inv<T, N, P, BLK><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
+                                                                        pl->half[1], pl->half[2], y2, y4, y8);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
 
-template <int N>
-static int launch_cols(int B, int W, int PT, int C, const sr_fbm_plan* pl, const float2* t1, float2* y2, float2* y4,
-                       float2* y8, float* pooled, int pooled_ld, hipStream_t st) {
+template <int N, bool BLK>
+static int launch_cols(int B, int W, int PT, int C, Inter im, const sr_fbm_plan* pl, const float2* t1, float2* y2,
+                       float2* y4, float2* y8, float* pooled, int pooled_ld, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
-    SR_HIP(hipFuncSetAttribute((const void*)cols<N, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    cols<N, P><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, pl->tw_h, pl->half[0], pl->half[1], pl->half[2],
-                                                                    pl->rowmask, t1, y2, y4, y8, pooled, pooled_ld, C);
+    SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cols<N, P, BLK><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1],
+                                                                         pl->half[2], pl->rowmask, t1, y2, y4, y8, pooled,
+                                                                         pooled_ld, C);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -343,6 +386,34 @@ static bool pow2_ok(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; 
         default: return SR_NOT_ELIGIBLE;  \
     }
 
+template <typename T>
+static int run_all(const sr_fbm_plan* pl, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
+                   int pooled_ld, void* ws, bool blk_x, bool blk_o, hipStream_t st) {
+    const int H = pl->H, W = pl->W, C = x.C;
+    const int PT = C / 2;
+    Inter im;
+    im.Q = pairs_for_rt(W) < pairs_for_rt(H) ? pairs_for_rt(W) : pairs_for_rt(H);
+    im.NPG = cdiv(PT, im.Q);
+    im.QL = im.Q == 16 ? 4 : (im.Q == 8 ? 3 : 2);
+    const size_t PTP = (size_t)im.NPG * im.Q;
+    const int n2 = pl->n[0], n4 = pl->n[1];
+    float2* t1 = (float2*)ws;
+    float2* y2 = t1 + (size_t)B * n2 * H * PTP;
+    float2* y4 = y2 + (size_t)B * H * n2 * PTP;
+    float2* y8 = y4 + (size_t)B * H * n4 * PTP;
+    const bool blk_c = im.Q == 4;  // 4-pair groups: butterflies of one group on consecutive lanes
+    int rc = SR_OK;
+    if (blk_x) { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, true>(x, ups, B, H, PT, im, pl, t1, st))); }
+    else { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, false>(x, ups, B, H, PT, im, pl, t1, st))); }
+    if (rc != SR_OK) return rc;
+    if (blk_c) { SR_DISPATCH_N(H, rc = (launch_cols<NN, true>(B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
+    else { SR_DISPATCH_N(H, rc = (launch_cols<NN, false>(B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
+    if (rc != SR_OK) return rc;
+    if (blk_o) { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, true>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, st))); }
+    else { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, false>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, st))); }
+    return rc;
+}
+
 }  // namespace fast
 
 int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
@@ -350,31 +421,18 @@ int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     using namespace fast;
     const int H = pl->H, W = pl->W, C = x.C;
     if (!pl->contiguous || !pow2_ok(H) || !pow2_ok(W) || (C & 1)) return SR_NOT_ELIGIBLE;
+    if ((long)x.bs >= (1L << 31) || (long)l2.bs >= (1L << 31) || (long)l4.bs >= (1L << 31) || (long)l8.bs >= (1L << 31) ||
+        (long)pl->n[0] * H * ((C / 2 + 15) / 16 * 16) >= (1L << 31))
+        return SR_NOT_ELIGIBLE;
     // pair loads / stores need 2-element alignment of every view
     const View* vs[4] = {&x, &l2, &l4, &l8};
     const size_t es = dtype_size(dtype);
     for (const View* v : vs)
-        if ((v->ld & 1) || (v->c0 & 1) || ((uintptr_t)v->p % (2 * es))) return SR_NOT_ELIGIBLE;
-    const int PT = C / 2;
-    const int n2 = pl->n[0], n4 = pl->n[1];
-    float2* t1 = (float2*)ws;
-    float2* y2 = t1 + (size_t)B * n2 * H * PT;
-    float2* y4 = y2 + (size_t)B * H * n2 * PT;
-    float2* y8 = y4 + (size_t)B * H * n4 * PT;
-    int rc = SR_OK;
-    if (dtype == SR_F32) {
-        SR_DISPATCH_N(W, rc = (launch_rows_fwd<float, NN>(x, ups, B, H, PT, pl, t1, st)));
-    } else {
-        SR_DISPATCH_N(W, rc = (launch_rows_fwd<bf16_t, NN>(x, ups, B, H, PT, pl, t1, st)));
-    }
-    if (rc != SR_OK) return rc;
-    SR_DISPATCH_N(H, rc = (launch_cols<NN>(B, W, PT, C, pl, t1, y2, y4, y8, pooled, pooled_ld, st)));
-    if (rc != SR_OK) return rc;
-    if (dtype == SR_F32) {
-        SR_DISPATCH_N(W, rc = (launch_rows_inv<float, NN>(l2, l4, l8, B, H, PT, pl, y2, y4, y8, st)));
-    } else {
-        SR_DISPATCH_N(W, rc = (launch_rows_inv<bf16_t, NN>(l2, l4, l8, B, H, PT, pl, y2, y4, y8, st)));
-    }
-    return rc;
+        if ((v->ld & 1) || (v->c0 & 1) || (v->cbs & 1) || (v->bs & 1) || ((uintptr_t)v->p % (2 * es))) return SR_NOT_ELIGIBLE;
+    // the row-major lane order pays for channel-blocked tensors (a row of 8 channels is contiguous)
+    auto is_blocked = [&](const View& v) { return v.ld == 8 && v.c0 % 8 == 0 && C % 8 == 0; };
+    const bool blk_x = is_blocked(x), blk_o = is_blocked(l2) && is_blocked(l4) && is_blocked(l8);
+    if (dtype == SR_F32) return run_all<float>(pl, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, blk_x, blk_o, st);
+    return run_all<bf16_t>(pl, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, blk_x, blk_o, st);
 }
 }  // namespace sr

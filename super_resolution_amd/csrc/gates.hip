@@ -26,7 +26,6 @@ __global__ __launch_bounds__(256) void fbm_gates_kernel(Concat in, int H, int W,
     float acc[3] = {0.f, 0.f, 0.f};
     for (int s = 0; s < in.nseg; ++s) {
         const View v = in.x[s];
-        const T* base = (const T*)v.p + (long)b * Hs * Ws * v.ld + v.c0;
         for (int cc = 0; cc < v.C; cc += GCC) {
             const int nc = min(GCC, v.C - cc);
             __syncthreads();
@@ -36,7 +35,7 @@ __global__ __launch_bounds__(256) void fbm_gates_kernel(Concat in, int H, int W,
                 const int h = ty0 + py - 1, w = tx0 + px - 1;
                 float val = 0.f;
                 if (h >= 0 && h < H && w >= 0 && w < W)
-                    val = Elem<T>::ld(base + ((long)(h >> in.ups) * Ws + (w >> in.ups)) * v.ld + cc + c);
+                    val = Elem<T>::ld((const T*)v.p + voff(v, b, (long)(h >> in.ups) * Ws + (w >> in.ups), cc + c));
                 tile[c][py][px] = val;
             }
             for (int it = threadIdx.x; it < 3 * nc * 9; it += blockDim.x) {
@@ -113,17 +112,16 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int H, int W, c
         const int py = slot / GPW, px = slot - py * GPW;
         const int h = h0 + py - 1, w = w0p + px - 1;
         const bool ok = slot < GSLOTS && h >= 0 && h < H && w >= 0 && w < W;
-        const long ps = ((long)b * Hs + (h >> in.ups)) * Ws + (w >> in.ups);
+        const long ps = (long)(h >> in.ups) * Ws + (w >> in.ups);
         g_float16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         int kc = 0;
         for (int s = 0; s < in.nseg; ++s) {
             const View v = in.x[s];
-            const bf16_t* px0 = (const bf16_t*)v.p + ps * v.ld + v.c0 + hk * 8;
             for (int cc = 0; cc < v.C; cc += 16, kc += 16) {
                 g_short8 bfrag = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) bfrag = *(const g_short8*)(px0 + cc);
+                if (ok) bfrag = *(const g_short8*)((const bf16_t*)v.p + voff(v, b, ps, cc + hk * 8));
                 const g_short8 afrag = *(const g_short8*)(A + r * astride + (kc + hk * 8) * 2);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
             }
@@ -160,7 +158,7 @@ static bool gates_mfma_eligible(const Concat& in) {
     if (in.ctot > 1024) return false;
     for (int s = 0; s < in.nseg; ++s) {
         const View& v = in.x[s];
-        if (v.C % 16 || v.c0 % 8 || v.ld % 8 || ((uintptr_t)v.p % 16)) return false;
+        if (v.C % 16 || !view_vec_ok(v, 8)) return false;
     }
     return true;
 }
@@ -194,11 +192,12 @@ using namespace sr;
 extern "C" int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in, const sr_layer_params* lp, float* gates,
                             void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && in && lp && gates);
+    SR_REQUIRE(!in->ups || (H % 2 == 0 && W % 2 == 0));
     Concat c;
-    int rc = to_concat(in, &c);
+    const long npix = (long)H * W;
+    int rc = to_concat(in, in->ups ? npix / 4 : npix, npix, &c);
     if (rc != SR_OK) return rc;
     SR_REQUIRE(c.ctot == lp->cin);
-    SR_REQUIRE(!c.ups || (H % 2 == 0 && W % 2 == 0));
     for (int k = 0; k < 3; ++k) SR_REQUIRE(lp->gate_w[k] && lp->gate_b[k]);
     return fbm_gates_launch(dtype, B, H, W, c, *lp, gates, (hipStream_t)stream);
 }

@@ -4,7 +4,7 @@
 namespace sr {
 thread_local int g_last_hip_error = 0;
 
-int to_concat(const sr_concat* in, Concat* out) {
+int to_concat(const sr_concat* in, long npix_x, long npix_bands, Concat* out) {
     if (!in || in->nseg < 1 || in->nseg > SR_MAX_SEG) return SR_ERR_ARG;
     Concat c{};
     c.nseg = in->nseg;
@@ -13,17 +13,17 @@ int to_concat(const sr_concat* in, Concat* out) {
     int tot = 0;
     for (int s = 0; s < in->nseg; ++s) {
         const sr_view& v = in->x[s];
-        if (!v.p || v.C < 1 || v.c0 < 0 || v.c0 + v.C > v.ld) return SR_ERR_ARG;
-        c.x[s] = to_view(v);
+        if (!v.p || v.C < 1 || v.c0 < 0 || v.ld < 1 || (!v.cbs && v.c0 + v.C > v.ld)) return SR_ERR_ARG;
+        c.x[s] = to_view(v, npix_x);
         c.cstart[s] = tot;
         tot += v.C;
         if (c.bands) {
             const sr_view* bs[3] = {&in->l2[s], &in->l4[s], &in->l8[s]};
             for (int k = 0; k < 3; ++k)
-                if (!bs[k]->p || bs[k]->C != v.C || bs[k]->c0 < 0 || bs[k]->c0 + v.C > bs[k]->ld) return SR_ERR_ARG;
-            c.l2[s] = to_view(in->l2[s]);
-            c.l4[s] = to_view(in->l4[s]);
-            c.l8[s] = to_view(in->l8[s]);
+                if (!bs[k]->p || bs[k]->C != v.C || bs[k]->c0 < 0 || (!bs[k]->cbs && bs[k]->c0 + v.C > bs[k]->ld)) return SR_ERR_ARG;
+            c.l2[s] = to_view(in->l2[s], npix_bands);
+            c.l4[s] = to_view(in->l4[s], npix_bands);
+            c.l8[s] = to_view(in->l8[s], npix_bands);
         }
     }
     for (int s = in->nseg; s <= SR_MAX_SEG; ++s) c.cstart[s] = tot;

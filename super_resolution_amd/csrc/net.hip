@@ -109,7 +109,10 @@ struct Run {
     size_t es;
     int rc = SR_OK;
 
-    View view(size_t off, int C) const { return View{ws + off, C, 0, C}; }
+    // LR tensors are NHWC; the 2x / 4x tensors are channel-blocked so the FFT passes stream whole rows
+    View view(size_t off, int C, long npix, bool blocked = false) const {
+        return (blocked && C % 8 == 0) ? blocked_view(ws + off, C, npix) : nhwc_view(ws + off, C, npix);
+    }
 
     void prof_begin(int group) {
         if (!net->prof || rc != SR_OK) return;
@@ -301,8 +304,9 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     const size_t n1 = (size_t)B * H * W, n2 = 4 * n1, n4 = 16 * n1;
     const int nf = n->nf, gc = n->gc;
 
-    auto with_bands = [&](Tensor& t, size_t band_off, size_t npix) {
-        for (int k = 0; k < 3; ++k) t.band[k] = View{R.ws + band_off + (size_t)k * npix * t.C * es, t.C, 0, t.C};
+    const long hw = (long)H * W;
+    auto with_bands = [&](Tensor& t, size_t band_off, size_t npix, bool blocked) {
+        for (int k = 0; k < 3; ++k) t.band[k] = R.view(band_off + (size_t)k * npix * t.C * es, t.C, (long)(npix / B), blocked);
     };
 
     // ---- pack input (pixel_unshuffle folded) --------------------------------------------------
@@ -313,22 +317,22 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
 
     Tensor tin;
     tin.C = n->cin0;
-    tin.x = R.view(L.in0, n->cin0);
+    tin.x = R.view(L.in0, n->cin0, hw);
     Tensor f0;
     f0.C = nf;
-    f0.x = R.view(L.f0, nf);
-    if (act) with_bands(f0, L.band64, n1);
+    f0.x = R.view(L.f0, nf, hw);
+    if (act) with_bands(f0, L.band64, n1, false);
     Tensor trunk[3];
     for (int i = 0; i < 3; ++i) {
         trunk[i].C = nf;
-        trunk[i].x = R.view(L.trunk[i], nf);
-        if (act) with_bands(trunk[i], L.band64, n1);  // one 64-channel band set: only the current RDB input is live
+        trunk[i].x = R.view(L.trunk[i], nf, hw);
+        if (act) with_bands(trunk[i], L.band64, n1, false);  // one 64-channel band set: only the current RDB input is live
     }
     Tensor xg[4];
     for (int i = 0; i < 4; ++i) {
         xg[i].C = gc;
-        xg[i].x = R.view(L.xg[i], gc);
-        if (act) with_bands(xg[i], L.bandg[i], n1);
+        xg[i].x = R.view(L.xg[i], gc, hw);
+        if (act) with_bands(xg[i], L.bandg[i], n1, false);
     }
 
     int li = 0;
@@ -380,10 +384,10 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     Tensor u1;
     u1.C = nf;
     u1.res = 1;
-    u1.x = R.view(L.u1, nf);
+    u1.x = R.view(L.u1, nf, 4 * hw, true);
     {
         g->bands_ready = false;
-        if (act) with_bands(*g, L.band_u1, n2);
+        if (act) with_bands(*g, L.band_u1, n2, true);
         Tensor* s[1] = {g};
         Epilogue ep{};
         ep.lrelu = 1;
@@ -393,9 +397,9 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     Tensor u2;
     u2.C = nf;
     u2.res = 2;
-    u2.x = R.view(L.u2, nf);
+    u2.x = R.view(L.u2, nf, 16 * hw, true);
     {
-        if (act) with_bands(u1, L.band_hr, n4);
+        if (act) with_bands(u1, L.band_hr, n4, true);
         Tensor* s[1] = {&u1};
         Epilogue ep{};
         ep.lrelu = 1;
@@ -405,9 +409,9 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     Tensor u3;
     u3.C = nf;
     u3.res = 2;
-    u3.x = R.view(L.u3, nf);
+    u3.x = R.view(L.u3, nf, 16 * hw, true);
     {
-        if (act) with_bands(u2, L.band_hr, n4);
+        if (act) with_bands(u2, L.band_hr, n4, true);
         Tensor* s[1] = {&u2};
         Epilogue ep{};
         ep.lrelu = 1;
@@ -415,9 +419,9 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     }
     {
         Tensor* s[1] = {&u3};
-        if (act) with_bands(u3, L.band_hr, n4);
+        if (act) with_bands(u3, L.band_hr, n4, true);
         Epilogue ep{};
-        R.conv(li++, s, 1, 2, ep, R.view(L.outp, n->out_ch));
+        R.conv(li++, s, 1, 2, ep, R.view(L.outp, n->out_ch, 16 * hw));
     }
     if (R.rc != SR_OK) return R.rc;
     R.prof_begin(G_LAYOUT);

@@ -38,6 +38,17 @@ def nchw(t):
     return t.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
+def blocked(t, dt=torch.float32):
+    """NCHW (C % 8 == 0) -> channel-blocked (B, C/8, H, W, 8) on the GPU."""
+    B, Cc, H, W = t.shape
+    return dev(t).view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(dt)
+
+
+def unblocked(t):
+    B, cb, H, W, _ = t.shape
+    return t.float().permute(0, 1, 4, 2, 3).reshape(B, cb * 8, H, W).cpu()
+
+
 def st(L):
     return L.stream_ptr(torch.device('cuda:0'))
 
@@ -151,6 +162,30 @@ def test_fbm_lowpass_pow2_upsampled_bf16(L):
     for k in range(3):
         assert (bands[k] - ref[k]).abs().max().item() < 4e-3
     assert (pooled - xu.mean(dim=(2, 3))).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('shape,ups', [((1, 16, 64, 128), 0), ((2, 8, 32, 64), 1), ((1, 8, 2048, 64), 0), ((1, 24, 40, 36), 0)])
+def test_fbm_lowpass_channel_blocked_layout(L, shape, ups):
+    """Channel-blocked tensors (the executor's 2x / 4x layout) through the same entry point."""
+    lib = L.lib()
+    x = torch.from_numpy(gp.signed_input(shape, 17))
+    B, Cc, H, W = x.shape
+    Ho, Wo = H << ups, W << ups
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(Ho, Wo, C.byref(plan)))
+    xb = blocked(x)
+    bands = [torch.full((B, Cc // 8, Ho, Wo, 8), float('nan'), device='cuda:0') for _ in range(3)]
+    pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+    L.check(lib.sr_fbm_lowpass(plan, 0, B, L.blocked_view(xb), ups, L.blocked_view(bands[0]), L.blocked_view(bands[1]),
+                               L.blocked_view(bands[2]), pooled.data_ptr(), Cc, ws.data_ptr(), ws.numel(), st(L)))
+    torch.cuda.synchronize()
+    lib.sr_fbm_plan_destroy(plan)
+    xu = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    ref = fr.fbm_lowpass(xu.double()).float()
+    for k in range(3):
+        assert (unblocked(bands[k]) - ref[k]).abs().max().item() < 2e-5, k
+    assert (pooled.cpu() - xu.mean(dim=(2, 3))).abs().max().item() < 1e-6
 
 
 def test_fbm_lowpass_upsampled_and_bf16(L):
@@ -388,6 +423,46 @@ def test_conv_mfma_bf16_plain(L, cin, cout, h, w):
     finally:
         L.lib().sr_debug_force_generic_conv(0)
     assert (got2 - ref).abs().max().item() < tol
+
+
+def test_conv_and_gates_channel_blocked_layout(L):
+    """bf16 MFMA conv + gates with channel-blocked activations, bands and output, NHWC upsampled source."""
+    lib = L.lib()
+    B, h, w, cin, cout = 2, 12, 20, 64, 64
+    H, W = 2 * h, 2 * w
+    x = bf(rnd((B, cin, h, w), 110))
+    bands = [bf(rnd((B, cin, H, W), 111 + k)) for k in range(3)]
+    keep = []
+    sd = gp.fdconv_params(cin, cout, 9)
+    lp, _ = make_lp(L, sd, cin, cout, torch.bfloat16, keep)
+    xn = nhwc(x, torch.bfloat16)
+    bb = [blocked(b_, torch.bfloat16) for b_ in bands]
+    cc = L.Concat()
+    cc.nseg, cc.ups, cc.bands = 1, 1, 1
+    cc.x[0] = L.view(xn)
+    cc.l2[0], cc.l4[0], cc.l8[0] = [L.blocked_view(b_) for b_ in bb]
+    gates = torch.full((B, H, W, 4), float('nan'), device='cuda:0')
+    L.check(lib.sr_fbm_gates(1, B, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st(L)))
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xu = F.interpolate(x, scale_factor=2, mode='nearest').double()
+    gref = fr.fbm_gates(xu, [t['FBM.freq_weight_conv_list.%d.weight' % i].to(torch.bfloat16).double() for i in range(3)],
+                        [t['FBM.freq_weight_conv_list.%d.bias' % i].double() for i in range(3)]).float()
+    torch.cuda.synchronize()
+    g3 = gates.cpu()[..., :3].permute(0, 3, 1, 2)
+    assert (g3 - gref).abs().max().item() < 2e-5
+    wt = bf(rnd((B, cout, cin, 3, 3), 115, 0.1))
+    wd = dev(wt.permute(0, 3, 4, 1, 2).reshape(B, 9, cout, cin)).contiguous().to(torch.bfloat16)
+    r1 = bf(rnd((B, cout, H, W), 116))
+    r1b = blocked(r1, torch.bfloat16)
+    ep = L.Epilogue()
+    ep.lrelu = 1
+    ep.r1, ep.s1 = L.blocked_view(r1b), 0.2
+    out = torch.full((B, cout // 8, H, W, 8), float('nan'), device='cuda:0', dtype=torch.bfloat16)
+    L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, cout, C.byref(ep),
+                           L.blocked_view(out), st(L)))
+    torch.cuda.synchronize()
+    ref = ref_conv([x], wt, lrelu=1, r1=r1, s1=0.2, bands=[bands], gates=g3, ups=1, per_sample=True)
+    assert (unblocked(out) - ref).abs().max().item() < 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
 
 def test_conv_mfma_bf16_bands_persample_ups(L):

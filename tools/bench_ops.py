@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single libsr_amd ops at the bench workload's shapes (for rocprofv3 / tuning).
+
+    python tools/bench_ops.py lowpass [C H W B reps]     python tools/bench_ops.py conv [cin cout H W B reps]
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from super_resolution_amd import _lib as L  # noqa: E402
+
+lib = L.lib()
+dev = torch.device('cuda:0')
+st = L.stream_ptr(dev)
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0):
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
+    shape = (B, Cc // 8, H, W, 8) if blocked else (B, H, W, Cc)
+    mk = L.blocked_view if blocked else L.view
+    x = torch.rand(shape, device=dev).to(torch.bfloat16)
+    bands = [torch.empty_like(x) for _ in range(3)]
+    pooled = torch.empty(B, Cc, device=dev)
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device=dev)
+
+    def run():
+        L.check(lib.sr_fbm_lowpass(plan, 1, B, mk(x), 0, mk(bands[0]), mk(bands[1]), mk(bands[2]), pooled.data_ptr(), Cc,
+                                   ws.data_ptr(), ws.numel(), st))
+    t = timeit(run, reps)
+    px = B * H * W * Cc
+    print('lowpass C=%d %dx%d B=%d blocked=%d: %.1f us  (%.2f B/px/ch algorithmic 8 -> %.2f TB/s)' %
+          (Cc, H, W, B, blocked, t * 1e6, 8.0, px * 8 / t / 1e12))
+
+
+def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1):
+    segs = [64] + [32] * ((cin - 64) // 32)
+    xs = [torch.rand(B, H, W, c, device=dev).to(torch.bfloat16) for c in segs]
+    bs = [[torch.rand(B, H, W, c, device=dev).to(torch.bfloat16) for _ in range(3)] for c in segs]
+    gates = torch.rand(B, H, W, 4, device=dev) * 2
+    wd = (torch.randn(B, 9, cout, cin, device=dev) * 0.05).to(torch.bfloat16)
+    out = torch.empty(B, H, W, cout, device=dev, dtype=torch.bfloat16)
+    cc = L.Concat()
+    cc.nseg, cc.bands = len(segs), bands
+    for i in range(len(segs)):
+        cc.x[i] = L.view(xs[i])
+        cc.l2[i], cc.l4[i], cc.l8[i] = [L.view(t) for t in bs[i]]
+    ep = L.Epilogue()
+    ep.lrelu = 1
+
+    def run():
+        L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, cout, C.byref(ep),
+                               L.view(out), st))
+    t = timeit(run, reps)
+    px = B * H * W
+    byts = px * ((4 if bands else 1) * cin * 2 + (16 if bands else 0) + cout * 2)
+    print('conv %d->%d %dx%d B=%d bands=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic' %
+          (cin, cout, H, W, B, bands, t * 1e6, 2.0 * 9 * cin * cout * px / t / 1e12, byts / t / 1e12))
+
+
+if __name__ == '__main__':
+    op = sys.argv[1]
+    args = [int(a) for a in sys.argv[2:]]
+    {'lowpass': lowpass, 'conv': conv}[op](*args)
