@@ -9,8 +9,8 @@ A step = one forward of RRDBNet(1,1,64,23,32) with every conv swapped for FDConv
 16 grayscale 512x512 images that is already resident in HBM, computed in bf16 (MFMA) through libsr_amd.
 The path shards by batch with no exchange step, so every rank runs the same per-GPU batch ("weak").
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
-  roofline     : the conv kernels (the dominant launch group), measured live with HIP events recorded by the
-                 executor on the launch stream around every conv launch of the timed steps;
+  roofline     : the conv kernels (the dominant launch group; HBM-bound on FDConv layers), measured live with HIP
+                 events recorded by the executor on the launch stream around every conv launch of the timed steps;
   cpu_baseline : the CPU oracle (torch fp32 restatement pinned by the golden fixtures) timed on this host on a
                  bounded sample of the same workload.
 """
@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 NUM_FEAT, NUM_BLOCK, NUM_GROW = 64, 23, 32
 
 
@@ -34,6 +35,29 @@ def conv_macs_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_GR
     """algorithmic conv MACs of RRDBNet x4 per LR pixel (17,905,056 for 1-channel I/O)."""
     rdb = 9 * (sum((nf + k * gc) * gc for k in range(4)) + (nf + 4 * gc) * nf)
     return 9 * cin0 * nf + 3 * nb * rdb + 9 * nf * nf * (1 + 4 + 16 + 16) + 16 * 9 * nf * cout_last
+
+
+def conv_bytes_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_GROW, es=2):
+    """SURVEY 8(d) / DESIGN.md 4: algorithmic HBM bytes of all conv launches of one forward, per LR pixel per sample.
+
+    An FDConv conv must read its input and the three low-pass planes of it (4 x cin elements per input pixel) plus
+    the three fp32 gates (12 B per input pixel), and write cout elements per output pixel; residual operands add
+    cout elements each; thin layers (conv_first / conv_last, min(c) <= 16) are plain convs.  Per-sample weights
+    are a few hundred KB per launch and are not counted.  `es` = bytes per activation element (2: bf16).
+    """
+    def fd(cin, cout, in_px, out_px, nres=0):
+        return in_px * (4 * cin * es + 12) + out_px * cout * es * (1 + nres)
+    tot = 1 * (cin0 * es) + 1 * nf * es                       # conv_first (plain)
+    for blk in range(3 * nb):
+        for k in range(4):
+            tot += fd(nf + k * gc, gc, 1, 1)
+        tot += fd(nf + 4 * gc, nf, 1, 1, nres=2 if blk % 3 == 2 else 1)
+    tot += fd(nf, nf, 1, 1, nres=1)                           # conv_body + trunk residual
+    tot += fd(nf, nf, 1, 4)                                   # conv_up1 reads LR, writes 2x
+    tot += fd(nf, nf, 4, 16)                                  # conv_up2 reads 2x, writes 4x
+    tot += fd(nf, nf, 16, 16)                                 # conv_hr
+    tot += 16 * nf * es + 16 * cout_last * es                 # conv_last (plain)
+    return tot
 
 
 def synthetic_batch(B, H, W, device, seed=1234):
@@ -80,6 +104,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--cpu-sample', type=int, default=96, help='side of the CPU-baseline sample image (0: skip)')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -130,7 +155,9 @@ def main():
     conv_ms, conv_n = prof['conv']
     conv_flops_step = 2.0 * conv_macs_per_lr_pixel(1, 1) * B * H * W
     conv_s_step = conv_ms / 1e3 / args.steps
-    achieved = conv_flops_step / conv_s_step / 1e12
+    tflops = conv_flops_step / conv_s_step / 1e12
+    conv_bytes_step = float(conv_bytes_per_lr_pixel(1, 1)) * B * H * W
+    gbs = conv_bytes_step / conv_s_step / 1e9
     res = {
         'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
         'value': out_mpix / (elapsed / args.steps),
@@ -148,15 +175,18 @@ def main():
                                'bf16 (BASELINE.json configs[1])' % (B, H, W),
                    'global_batch': world * B, 'parallelism': 'batch-sharded replicas x%d, no exchange' % world,
                    'output_finite': finite},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_bf16 (all %d conv launches per step)' % (conv_n // args.steps),
-                     'achieved': achieved, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
-                     'avg_launch_ms': conv_ms / max(conv_n, 1), 'algorithmic_tflop_per_step': conv_flops_step / 1e12},
+        # the FDConv conv streams 4 tensors per input channel: ~70 FLOP/B, far left of the 312 FLOP/B ridge -> HBM-bound
+        'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_mfma_bf16 (average over the %d conv launches of a step)' % (conv_n // args.steps),
+                     'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                     'avg_launch_ms': conv_ms / max(conv_n, 1),
+                     'algorithmic_gb_per_launch': conv_bytes_step / 1e9 / max(conv_n // args.steps, 1),
+                     'mfma': {'achieved': tflops, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': tflops / BF16_MFMA_PEAK_TFLOPS, 'algorithmic_tflop_per_step': conv_flops_step / 1e12}},
         'kernel_ms_per_step': {k: v[0] / args.steps for k, v in prof.items()},
         'kernel_launches_per_step': {k: v[1] // args.steps for k, v in prof.items()},
     }
     if rank == 0:
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(sd, args.cpu_sample)
         print(json.dumps(res))
     if world > 1:

@@ -39,18 +39,20 @@ extern "C" {
 
 #define SR_MAX_SEG 8 /* max tensors in a virtual channel concat */
 
-/* A view of `C` channels of an activation tensor.  Element (b, pixel, c) with cc = c0 + c lives at
- *     b*bs + (cc / 8)*cbs + pixel*ld + (cc % 8)            (in elements, pixel = h*W + w).
- * NHWC is ld = channels of the underlying tensor, cbs = 8, bs = H*W*ld; leaving cbs = bs = 0 selects
- * exactly that.  The channel-blocked layout [B][C/8][H][W][8] (what the executor uses for the 2x / 4x
- * resolution tensors so that an image row of 8 channels is contiguous for the FFT passes) is
- * ld = 8, cbs = 8*H*W, bs = C*H*W. */
+/* A view of `C` channels of an activation tensor.  Two layouts:
+ *   NHWC (cbs = 0):  element (b, pixel, c), cc = c0 + c, lives at  b*bs + pixel*ld + cc  (pixel = h*W + w, in
+ *     elements); ld = channels of the underlying tensor, bs = H*W*ld (bs = 0 selects exactly that).
+ *   channel-blocked [B][C/cb][H][W][cb] (cbs != 0), cb = ld a power of two >= 8:
+ *     b*bs + (cc / cb)*cbs + pixel*cb + (cc % cb),  cbs = cb*H*W, bs = C*H*W.
+ *     The executor keeps trunk tensors in blocks of 32 channels (a conv K-chunk is then one contiguous 64-byte
+ *     run per pixel, a tile row one contiguous run) and the 2x / 4x tensors in blocks of 8 (an image row of 8
+ *     channels is contiguous for the FFT passes). */
 typedef struct {
     void* p;     /* base of the underlying tensor */
     int32_t ld;  /* elements between consecutive pixels */
     int32_t c0;  /* first channel of the view */
     int32_t C;   /* channels in the view */
-    int32_t cbs; /* elements between consecutive 8-channel blocks (0: NHWC) */
+    int32_t cbs; /* elements between consecutive channel blocks (0: NHWC) */
     int64_t bs;  /* elements between consecutive samples (0: NHWC, H*W*ld) */
 } sr_view;
 

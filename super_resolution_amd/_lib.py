@@ -125,10 +125,10 @@ def view(t, C_=None, c0=0):
 
 
 def blocked_view(t):
-    """sr_view over a channel-blocked tensor of shape (B, C/8, H, W, 8)."""
-    B, cb, H, W, e = t.shape
-    assert e == 8 and t.is_contiguous()
-    return View(t.data_ptr(), 8, 0, cb * 8, 8 * H * W, cb * 8 * H * W)
+    """sr_view over a channel-blocked tensor of shape (B, C/cb, H, W, cb), cb a power of two >= 8."""
+    B, nb, H, W, e = t.shape
+    assert e >= 8 and e & (e - 1) == 0 and t.is_contiguous()
+    return View(t.data_ptr(), e, 0, nb * e, e * H * W, nb * e * H * W)
 
 
 def null_view():

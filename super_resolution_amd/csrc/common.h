@@ -52,30 +52,49 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // device-side mirrors of the ABI structs (plain data, passed by value as kernel arguments)
+// Channel-blocked tensors keep 2^csh channels per block ([B][C >> csh][pixels][1 << csh], ld == 1 << csh);
+// NHWC is the degenerate case csh = 3, cbs = 8 (block term + in-block term add up to the channel index).
 struct View {
     char* p;
-    int ld, c0, C, cbs;
+    int ld, c0, C, cbs, csh;
     long bs;
 };
 // element offset of channel c of pixel `pix` (h*W + w of the view's own resolution) of sample b
 __host__ __device__ __forceinline__ long voff(const View& v, int b, long pix, int c) {
     const int cc = v.c0 + c;
-    return (long)b * v.bs + (long)(cc >> 3) * v.cbs + pix * v.ld + (cc & 7);
+    return (long)b * v.bs + (long)(cc >> v.csh) * v.cbs + pix * v.ld + (cc & ((1 << v.csh) - 1));
 }
 // same without the sample term, in 32 bits (a sample is < 2^31 elements; checked on the host)
 __device__ __forceinline__ unsigned voff32(const View& v, unsigned pix, int c) {
     const unsigned cc = (unsigned)(v.c0 + c);
-    return (cc >> 3) * (unsigned)v.cbs + pix * (unsigned)v.ld + (cc & 7u);
+    return (cc >> v.csh) * (unsigned)v.cbs + pix * (unsigned)v.ld + (cc & ((1u << v.csh) - 1u));
 }
 // npix: pixels per sample of the viewed tensor (fills the NHWC defaults)
+// a blocked sr_view (cbs != 0) keeps ld channels per block; ld must then be a power of two >= 8 (view_block_ok)
+inline bool view_block_ok(const sr_view& v) { return !v.cbs || (v.ld >= 8 && (v.ld & (v.ld - 1)) == 0); }
 inline View to_view(const sr_view& v, long npix) {
-    return View{(char*)v.p, v.ld, v.c0, v.C, v.cbs ? v.cbs : 8, v.bs ? (long)v.bs : npix * v.ld};
+    int csh = 3;
+    if (v.cbs)
+        while ((1 << csh) < v.ld) ++csh;
+    return View{(char*)v.p, v.ld, v.c0, v.C, v.cbs ? v.cbs : 8, csh, v.bs ? (long)v.bs : npix * v.ld};
 }
-inline View nhwc_view(void* p, int C, long npix) { return View{(char*)p, C, 0, C, 8, npix * C}; }
-inline View blocked_view(void* p, int C, long npix) { return View{(char*)p, 8, 0, C, (int)(8 * npix), npix * C}; }
+inline View nhwc_view(void* p, int C, long npix) { return View{(char*)p, C, 0, C, 8, 3, npix * C}; }
+// cb = channels per block (8 or 32)
+inline View blocked_view(void* p, int C, long npix, int cb = 8) {
+    int csh = 3;
+    while ((1 << csh) < cb) ++csh;
+    return View{(char*)p, cb, 0, C, (int)(cb * npix), csh, npix * C};
+}
 // 16-byte vector access to 8-channel groups / 8-byte access to 4-channel groups is legal
 inline bool view_vec_ok(const View& v, int mult) {
     return v.p && ((uintptr_t)v.p % 16 == 0) && v.ld % mult == 0 && v.c0 % mult == 0 && v.cbs % 8 == 0 && v.bs % 8 == 0;
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Map launch index L of T so that every XCD
+// walks one contiguous range of the logical index space: neighbouring tiles (shared halos) then meet in one L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned L, unsigned T) {
+    const unsigned q = T >> 3, r = T & 7u, x = L & 7u, i = L >> 3;
+    return x * q + (x < r ? x : r) + i;
 }
 
 struct Concat {

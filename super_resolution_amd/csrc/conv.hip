@@ -255,109 +255,151 @@ __device__ __forceinline__ bool advance(const Concat& in, ChunkCursor& cur) {
     return cur.s < in.nseg;
 }
 
+// Tile walk of one persistent workgroup.  Workgroups are dealt round-robin to the XCDs, so workgroup j lives on
+// XCD j % 8; each XCD owns one contiguous range of the (tile, sample, cout block) index space and its workgroups
+// stride through it together, so the tiles resident on an XCD at any time are neighbours (halo rows meet in L2).
+struct TileWalk {
+    unsigned next, end, stride;
+    __device__ __forceinline__ TileWalk(unsigned total) {
+        const unsigned j = blockIdx.x, x = j & 7u, q = total >> 3, r = total & 7u;
+        const unsigned start = x * q + (x < r ? x : r);
+        end = start + q + (x < r ? 1u : 0u);
+        // workgroups on this XCD: ceil((gridDim - x) / 8)
+        stride = (gridDim.x - x + 7u) >> 3;
+        next = start + (j >> 3);
+    }
+};
+
+struct TileId {
+    int b, o_blk, h0, w0;
+};
+template <int MT>
+__device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int tilesx, int B) {
+    TileId t;
+    const int tile = lin % tiles;
+    lin /= tiles;
+    t.b = lin % (unsigned)B;
+    t.o_blk = (lin / (unsigned)B) * (MT * 32);
+    t.h0 = (tile / tilesx) * MTH;
+    t.w0 = (tile % tilesx) * MTW;
+    return t;
+}
+
 template <int MT, bool BANDS>
-__global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int H, int W, const float* __restrict__ gates,
+__global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, int cin,
-                                                         int cout, Epilogue ep, View out) {
+                                                         int cout, Epilogue ep, View out, unsigned total) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int STAGE = NPIX * 64 + 9 * MT * 32 * 64;  // pixel tile + weight slab
+    constexpr int STAGE_PX = NPIX * 64;
     const int tilesx = (W + MTW - 1) / MTW;
-    const int b = blockIdx.y;
-    const int o_blk = blockIdx.z * (MT * 32);
-    const int h0 = (blockIdx.x / tilesx) * MTH, w0 = (blockIdx.x % tilesx) * MTW;
+    const unsigned tiles = (unsigned)tilesx * ((H + MTH - 1) / MTH);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;
     const int r = lane & 31, hk = lane >> 5;
-    const bf16_t* wb = wts + (long)b * w_bstride;
-
     const int nchunks = cin / 32;
-    constexpr int STAGE_PX = NPIX * 64;
+    TileWalk walk(total);
+    if (walk.next >= walk.end) return;  // whole workgroup: no barrier is skipped by a subset of waves
+
     if (loader) {
-        // ---- producer waves: never touch the accumulators (separate register budget) --------------
-        ChunkCursor cur{0, 0, 0};
-        stage_chunk<MT, BANDS>(in, cur, b, H, W, h0, w0, gates, wb, cin, cout, o_blk, lds, lds + STAGE_PX, tid - 256);
-        __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            if (advance(in, cur)) {
-                char* nxt = lds + ((c + 1) & 1) * STAGE;
-                stage_chunk<MT, BANDS>(in, cur, b, H, W, h0, w0, gates, wb, cin, cout, o_blk, nxt, nxt + STAGE_PX, tid - 256);
+        // ---- producer waves: never touch the accumulators (separate register budget).  They run one chunk
+        // ahead of the MFMA waves across tile boundaries, so a tile's first chunk streams in while the previous
+        // tile is still being multiplied and written out.
+        unsigned step = 0;
+        for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
+            const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
+            const bf16_t* wb = wts + (long)t.b * w_bstride;
+            ChunkCursor cur{0, 0, 0};
+            for (int c = 0; c < nchunks; ++c) {
+                char* dst = lds + (step & 1) * STAGE;
+                stage_chunk<MT, BANDS>(in, cur, t.b, H, W, t.h0, t.w0, gates, wb, cin, cout, t.o_blk, dst, dst + STAGE_PX,
+                                       tid - 256);
+                advance(in, cur);
+                __syncthreads();  // stage `step` is full; stage `step - 1` has been consumed
+                ++step;
             }
-            __syncthreads();
         }
+        __syncthreads();  // pairs with the consumers' barrier after the last chunk
         return;
     }
-    float16v acc[MT][4];
+    unsigned step = 0;
+    __syncthreads();  // stage 0 is full
+    for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
+        const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
+        const int b = t.b, o_blk = t.o_blk, h0 = t.h0, w0 = t.w0;
+        float16v acc[MT][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const char* cur_px = lds + (c & 1) * STAGE;
-        const char* cur_w = cur_px + STAGE_PX;
+                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            const char* cur_px = lds + (step & 1) * STAGE;
+            const char* cur_w = cur_px + STAGE_PX;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int chunk = kk * 2 + hk;
-                short8 af[MT];
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int chunk = kk * 2 + hk;
+                    short8 af[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = *(const short8*)(cur_w + swz(tap * (MT * 32) + m * 32 + r, chunk));
+                    for (int m = 0; m < MT; ++m) af[m] = *(const short8*)(cur_w + swz(tap * (MT * 32) + m * 32 + r, chunk));
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int pi = (wave * 4 + n + dy) * PW + r + dx;
-                    const short8 bf = *(const short8*)(cur_px + swz(pi, chunk));
+                    for (int n = 0; n < 4; ++n) {
+                        const int pi = (wave * 4 + n + dy) * PW + r + dx;
+                        const short8 bf = *(const short8*)(cur_px + swz(pi, chunk));
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
+                    }
                 }
             }
+            __syncthreads();  // stage `step` consumed; stage `step + 1` is full
+            ++step;
         }
-        __syncthreads();
-    }
-    // ---- epilogue: lane holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each tile ----
-    const int w = w0 + r;
+        // ---- epilogue: lane holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each tile ----
+        const int w = w0 + r;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int h = h0 + wave * 4 + n;
-        if (h >= H || w >= W) continue;
-        const long pix = (long)h * W + w;
+        for (int n = 0; n < 4; ++n) {
+            const int h = h0 + wave * 4 + n;
+            if (h >= H || w >= W) continue;
+            const long pix = (long)h * W + w;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+            for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = o_blk + m * 32 + q * 8 + hk * 4;
-                if (o >= cout) continue;
-                float y[4];
+                for (int q = 0; q < 4; ++q) {
+                    const int o = o_blk + m * 32 + q * 8 + hk * 4;
+                    if (o >= cout) continue;
+                    float y[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = acc[m][n][q * 4 + j] + (ep.bias ? ep.bias[o + j] : 0.f);
-                if (ep.lrelu) {
+                    for (int j = 0; j < 4; ++j) y[j] = acc[m][n][q * 4 + j] + (ep.bias ? ep.bias[o + j] : 0.f);
+                    if (ep.lrelu) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = lrelu02(y[j]);
+                        for (int j = 0; j < 4; ++j) y[j] = lrelu02(y[j]);
+                    }
+                    if (ep.r1.p) {
+                        const uint2 rr = *(const uint2*)((const bf16_t*)ep.r1.p + voff(ep.r1, b, pix, o));
+                        y[0] = y[0] * ep.s1 + lo_f(rr.x);
+                        y[1] = y[1] * ep.s1 + hi_f(rr.x);
+                        y[2] = y[2] * ep.s1 + lo_f(rr.y);
+                        y[3] = y[3] * ep.s1 + hi_f(rr.y);
+                    }
+                    if (ep.r2.p) {
+                        const uint2 rr = *(const uint2*)((const bf16_t*)ep.r2.p + voff(ep.r2, b, pix, o));
+                        y[0] = y[0] * ep.s2 + lo_f(rr.x);
+                        y[1] = y[1] * ep.s2 + hi_f(rr.x);
+                        y[2] = y[2] * ep.s2 + lo_f(rr.y);
+                        y[3] = y[3] * ep.s2 + hi_f(rr.y);
+                    }
+                    uint2 st;
+                    st.x = pack2(y[0], y[1]);
+                    st.y = pack2(y[2], y[3]);
+                    *(uint2*)((bf16_t*)out.p + voff(out, b, pix, o)) = st;
                 }
-                if (ep.r1.p) {
-                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r1.p + voff(ep.r1, b, pix, o));
-                    y[0] = y[0] * ep.s1 + lo_f(rr.x);
-                    y[1] = y[1] * ep.s1 + hi_f(rr.x);
-                    y[2] = y[2] * ep.s1 + lo_f(rr.y);
-                    y[3] = y[3] * ep.s1 + hi_f(rr.y);
-                }
-                if (ep.r2.p) {
-                    const uint2 rr = *(const uint2*)((const bf16_t*)ep.r2.p + voff(ep.r2, b, pix, o));
-                    y[0] = y[0] * ep.s2 + lo_f(rr.x);
-                    y[1] = y[1] * ep.s2 + hi_f(rr.x);
-                    y[2] = y[2] * ep.s2 + lo_f(rr.y);
-                    y[3] = y[3] * ep.s2 + hi_f(rr.y);
-                }
-                uint2 st;
-                st.x = pack2(y[0], y[1]);
-                st.y = pack2(y[2], y[3]);
-                *(uint2*)((bf16_t*)out.p + voff(out, b, pix, o)) = st;
             }
         }
     }
@@ -391,8 +433,16 @@ static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates
                                    (int)ldsb));
         attr_set = true;
     }
-    dim3 grid(cdiv(H, MTH) * cdiv(W, MTW), B, cdiv(cout, MT * 32));
-    conv3x3_mfma_bf16<MT, BANDS><<<grid, 512, ldsb, st>>>(in, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out);
+    const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
+    if (nblk >= (1L << 31)) return SR_ERR_ARG;
+    static int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
+    if (!ncu) {
+        int dev = 0;
+        SR_HIP(hipGetDevice(&dev));
+        SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
+    conv3x3_mfma_bf16<MT, BANDS><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out, (unsigned)nblk);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -426,7 +476,8 @@ extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, c
     int rc = to_concat(in, in->ups ? npix / 4 : npix, npix, &c);
     if (rc != SR_OK) return rc;
     SR_REQUIRE(!c.bands || gates);
-    SR_REQUIRE(out.C == cout && out.c0 >= 0 && (out.cbs || out.c0 + cout <= out.ld));
+    SR_REQUIRE(out.C == cout && out.c0 >= 0 && (out.cbs || out.c0 + cout <= out.ld) && view_block_ok(out));
+    SR_REQUIRE(!ep || (view_block_ok(ep->r1) && view_block_ok(ep->r2)));
     Epilogue e = to_epilogue(ep, npix);
     SR_REQUIRE(!e.r1.p || e.r1.C == cout);
     SR_REQUIRE(!e.r2.p || e.r2.C == cout);

@@ -429,6 +429,7 @@ extern "C" int sr_fbm_lowpass(const sr_fbm_plan* pl, int dtype, int B, sr_view x
     SR_REQUIRE(pl && dtype_ok(dtype) && B > 0 && x.p && l2.p && l4.p && l8.p && ws);
     SR_REQUIRE(x.C > 0 && l2.C == x.C && l4.C == x.C && l8.C == x.C);
     SR_REQUIRE(x.c0 >= 0 && l2.c0 >= 0 && l4.c0 >= 0 && l8.c0 >= 0);
+    SR_REQUIRE(view_block_ok(x) && view_block_ok(l2) && view_block_ok(l4) && view_block_ok(l8));
     SR_REQUIRE(ups == 0 || (pl->H % 2 == 0 && pl->W % 2 == 0));
     SR_REQUIRE(!pooled || pooled_ld >= x.C);
     const long npix = (long)pl->H * pl->W;

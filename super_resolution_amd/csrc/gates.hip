@@ -83,7 +83,7 @@ constexpr int GSLOTS = GPH * GPW;
 constexpr int GNT = (GSLOTS + 31) / 32;          // 11 N-tiles of 32 slots
 constexpr int GTROW = 27;                        // floats per slot in the T image (odd: conflict-free)
 
-__global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int H, int W, const float* __restrict__ w0,
+__global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, int W, const float* __restrict__ w0,
                                                       const float* __restrict__ w1, const float* __restrict__ w2,
                                                       const float* __restrict__ b0, const float* __restrict__ b1,
                                                       const float* __restrict__ b2, float* __restrict__ gates) {
@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int H, int W, c
     const int cin = in.ctot;
     const int astride = cin * 2 + 16;
     const int tilesx = (W + GMW - 1) / GMW;
-    const int b = blockIdx.y;
-    const int h0 = (blockIdx.x / tilesx) * GMH, w0p = (blockIdx.x % tilesx) * GMW;
+    const unsigned tiles = (unsigned)tilesx * ((H + GMH - 1) / GMH);
+    const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);  // (tile, sample), tile fastest, XCD-contiguous
+    const int tile = lin % tiles, b = lin / tiles;
+    const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hk = lane >> 5;
     const int Hs = H >> in.ups, Ws = W >> in.ups;
@@ -170,8 +172,10 @@ int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_
     if (dtype == SR_BF16 && !g_force_generic_gates && gates_mfma_eligible(in)) {
         const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + 32ul * (in.ctot * 2 + 16);
         SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        fbm_gates_mfma<<<dim3(cdiv(H, GMH) * cdiv(W, GMW), B), 256, lds, st>>>(
-            in, H, W, lp.gate_w[0], lp.gate_w[1], lp.gate_w[2], lp.gate_b[0], lp.gate_b[1], lp.gate_b[2], gates);
+        const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
+        if (nblk >= (1L << 31)) return SR_ERR_ARG;
+        fbm_gates_mfma<<<dim3((unsigned)nblk), 256, lds, st>>>(
+            in, B, H, W, lp.gate_w[0], lp.gate_w[1], lp.gate_w[2], lp.gate_b[0], lp.gate_b[1], lp.gate_b[2], gates);
         SR_LAUNCH_CHECK();
         return SR_OK;
     }

@@ -13,14 +13,16 @@ int to_concat(const sr_concat* in, long npix_x, long npix_bands, Concat* out) {
     int tot = 0;
     for (int s = 0; s < in->nseg; ++s) {
         const sr_view& v = in->x[s];
-        if (!v.p || v.C < 1 || v.c0 < 0 || v.ld < 1 || (!v.cbs && v.c0 + v.C > v.ld)) return SR_ERR_ARG;
+        if (!v.p || v.C < 1 || v.c0 < 0 || v.ld < 1 || (!v.cbs && v.c0 + v.C > v.ld) || !view_block_ok(v)) return SR_ERR_ARG;
         c.x[s] = to_view(v, npix_x);
         c.cstart[s] = tot;
         tot += v.C;
         if (c.bands) {
             const sr_view* bs[3] = {&in->l2[s], &in->l4[s], &in->l8[s]};
             for (int k = 0; k < 3; ++k)
-                if (!bs[k]->p || bs[k]->C != v.C || bs[k]->c0 < 0 || (!bs[k]->cbs && bs[k]->c0 + v.C > bs[k]->ld)) return SR_ERR_ARG;
+                if (!bs[k]->p || bs[k]->C != v.C || bs[k]->c0 < 0 || (!bs[k]->cbs && bs[k]->c0 + v.C > bs[k]->ld) ||
+                    !view_block_ok(*bs[k]))
+                    return SR_ERR_ARG;
             c.l2[s] = to_view(in->l2[s], npix_bands);
             c.l4[s] = to_view(in->l4[s], npix_bands);
             c.l8[s] = to_view(in->l8[s], npix_bands);

@@ -109,9 +109,10 @@ struct Run {
     size_t es;
     int rc = SR_OK;
 
-    // LR tensors are NHWC; the 2x / 4x tensors are channel-blocked so the FFT passes stream whole rows
-    View view(size_t off, int C, long npix, bool blocked = false) const {
-        return (blocked && C % 8 == 0) ? blocked_view(ws + off, C, npix) : nhwc_view(ws + off, C, npix);
+    // cb = channels per block (0: NHWC).  Trunk tensors use blocks of 32 (one conv K-chunk = one contiguous 64-byte
+    // run per pixel); the 2x / 4x tensors blocks of 8, so the FFT passes stream whole rows.
+    View view(size_t off, int C, long npix, int cb = 0) const {
+        return (cb && C % cb == 0) ? blocked_view(ws + off, C, npix, cb) : nhwc_view(ws + off, C, npix);
     }
 
     void prof_begin(int group) {
@@ -305,8 +306,8 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     const int nf = n->nf, gc = n->gc;
 
     const long hw = (long)H * W;
-    auto with_bands = [&](Tensor& t, size_t band_off, size_t npix, bool blocked) {
-        for (int k = 0; k < 3; ++k) t.band[k] = R.view(band_off + (size_t)k * npix * t.C * es, t.C, (long)(npix / B), blocked);
+    auto with_bands = [&](Tensor& t, size_t band_off, size_t npix, int cb) {
+        for (int k = 0; k < 3; ++k) t.band[k] = R.view(band_off + (size_t)k * npix * t.C * es, t.C, (long)(npix / B), cb);
     };
 
     // ---- pack input (pixel_unshuffle folded) --------------------------------------------------
@@ -320,19 +321,19 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     tin.x = R.view(L.in0, n->cin0, hw);
     Tensor f0;
     f0.C = nf;
-    f0.x = R.view(L.f0, nf, hw);
-    if (act) with_bands(f0, L.band64, n1, false);
+    f0.x = R.view(L.f0, nf, hw, 32);
+    if (act) with_bands(f0, L.band64, n1, 32);
     Tensor trunk[3];
     for (int i = 0; i < 3; ++i) {
         trunk[i].C = nf;
-        trunk[i].x = R.view(L.trunk[i], nf, hw);
-        if (act) with_bands(trunk[i], L.band64, n1, false);  // one 64-channel band set: only the current RDB input is live
+        trunk[i].x = R.view(L.trunk[i], nf, hw, 32);
+        if (act) with_bands(trunk[i], L.band64, n1, 32);  // one 64-channel band set: only the current RDB input is live
     }
     Tensor xg[4];
     for (int i = 0; i < 4; ++i) {
         xg[i].C = gc;
-        xg[i].x = R.view(L.xg[i], gc, hw);
-        if (act) with_bands(xg[i], L.bandg[i], n1, false);
+        xg[i].x = R.view(L.xg[i], gc, hw, 32);
+        if (act) with_bands(xg[i], L.bandg[i], n1, 32);
     }
 
     int li = 0;
@@ -384,10 +385,10 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     Tensor u1;
     u1.C = nf;
     u1.res = 1;
-    u1.x = R.view(L.u1, nf, 4 * hw, true);
+    u1.x = R.view(L.u1, nf, 4 * hw, 8);
     {
         g->bands_ready = false;
-        if (act) with_bands(*g, L.band_u1, n2, true);
+        if (act) with_bands(*g, L.band_u1, n2, 8);
         Tensor* s[1] = {g};
         Epilogue ep{};
         ep.lrelu = 1;
@@ -397,9 +398,9 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     Tensor u2;
     u2.C = nf;
     u2.res = 2;
-    u2.x = R.view(L.u2, nf, 16 * hw, true);
+    u2.x = R.view(L.u2, nf, 16 * hw, 8);
     {
-        if (act) with_bands(u1, L.band_hr, n4, true);
+        if (act) with_bands(u1, L.band_hr, n4, 8);
         Tensor* s[1] = {&u1};
         Epilogue ep{};
         ep.lrelu = 1;
@@ -409,9 +410,9 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     Tensor u3;
     u3.C = nf;
     u3.res = 2;
-    u3.x = R.view(L.u3, nf, 16 * hw, true);
+    u3.x = R.view(L.u3, nf, 16 * hw, 8);
     {
-        if (act) with_bands(u2, L.band_hr, n4, true);
+        if (act) with_bands(u2, L.band_hr, n4, 8);
         Tensor* s[1] = {&u2};
         Epilogue ep{};
         ep.lrelu = 1;
@@ -419,7 +420,7 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
     }
     {
         Tensor* s[1] = {&u3};
-        if (act) with_bands(u3, L.band_hr, n4, true);
+        if (act) with_bands(u3, L.band_hr, n4, 8);
         Epilogue ep{};
         R.conv(li++, s, 1, 2, ep, R.view(L.outp, n->out_ch, 16 * hw));
     }

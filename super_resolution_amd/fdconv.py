@@ -13,6 +13,8 @@ Only the default-kwargs configuration used by the owner scripts
 import ctypes as C
 import math
 
+import logging
+
 import torch
 import torch.nn as nn
 
@@ -20,6 +22,8 @@ from . import _lib as L
 
 _DEFAULT_FBM_CFG = {'k_list': [2, 4, 8], 'lowfreq_att': False, 'fs_feat': 'feat', 'act': 'sigmoid', 'spatial': 'conv',
                     'spatial_group': 1, 'spatial_kernel': 3, 'init': 'zero', 'global_selection': False}
+
+_log = logging.getLogger(__name__)
 
 
 def get_fft2freq(d1, d2, use_rfft=False):
@@ -138,7 +142,7 @@ class FDConv(nn.Conv2d):
         cin, cout = self.in_channels, self.out_channels
         if cin % 2 or (3 * cout * (3 * cin // 2 + 1)) % kernel_num:
             raise ValueError('FDConv needs an even in_channels and an rfft2 grid divisible by kernel_num')
-        print('*** kernel_num:', self.kernel_num)
+        _log.debug('kernel_num: %d', self.kernel_num)  # the reference prints this line to stdout (FDConv.py:566)
         self.alpha = min(cout, cin) // 2 * self.kernel_num * self.param_ratio / param_reduction
         self.KSM_Global = KernelSpatialModulation_Global(cin, cout, 3, kernel_num, reduction=reduction, stride=self.stride)
         self.FBM = FrequencyBandModulation(cin, fbm_cfg['k_list'])

@@ -38,15 +38,15 @@ def nchw(t):
     return t.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
-def blocked(t, dt=torch.float32):
-    """NCHW (C % 8 == 0) -> channel-blocked (B, C/8, H, W, 8) on the GPU."""
+def blocked(t, dt=torch.float32, cb=8):
+    """NCHW (C % cb == 0) -> channel-blocked (B, C/cb, H, W, cb) on the GPU."""
     B, Cc, H, W = t.shape
-    return dev(t).view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(dt)
+    return dev(t).view(B, Cc // cb, cb, H, W).permute(0, 1, 3, 4, 2).contiguous().to(dt)
 
 
 def unblocked(t):
-    B, cb, H, W, _ = t.shape
-    return t.float().permute(0, 1, 4, 2, 3).reshape(B, cb * 8, H, W).cpu()
+    B, nb, H, W, cb = t.shape
+    return t.float().permute(0, 1, 4, 2, 3).reshape(B, nb * cb, H, W).cpu()
 
 
 def st(L):
@@ -164,17 +164,19 @@ def test_fbm_lowpass_pow2_upsampled_bf16(L):
     assert (pooled - xu.mean(dim=(2, 3))).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize('shape,ups', [((1, 16, 64, 128), 0), ((2, 8, 32, 64), 1), ((1, 8, 2048, 64), 0), ((1, 24, 40, 36), 0)])
-def test_fbm_lowpass_channel_blocked_layout(L, shape, ups):
-    """Channel-blocked tensors (the executor's 2x / 4x layout) through the same entry point."""
+@pytest.mark.parametrize('shape,ups,cb', [((1, 16, 64, 128), 0, 8), ((2, 8, 32, 64), 1, 8), ((1, 8, 2048, 64), 0, 8),
+                                          ((1, 24, 40, 36), 0, 8), ((2, 64, 64, 128), 0, 32), ((1, 32, 32, 64), 1, 32),
+                                          ((1, 64, 40, 36), 0, 32), ((1, 32, 64, 64), 0, 16)])
+def test_fbm_lowpass_channel_blocked_layout(L, shape, ups, cb):
+    """Channel-blocked tensors (blocks of 8: the executor's 2x / 4x layout; of 32: its trunk layout)."""
     lib = L.lib()
     x = torch.from_numpy(gp.signed_input(shape, 17))
     B, Cc, H, W = x.shape
     Ho, Wo = H << ups, W << ups
     plan = C.c_void_p()
     L.check(lib.sr_fbm_plan_create(Ho, Wo, C.byref(plan)))
-    xb = blocked(x)
-    bands = [torch.full((B, Cc // 8, Ho, Wo, 8), float('nan'), device='cuda:0') for _ in range(3)]
+    xb = blocked(x, cb=cb)
+    bands = [torch.full((B, Cc // cb, Ho, Wo, cb), float('nan'), device='cuda:0') for _ in range(3)]
     pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
     ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
     L.check(lib.sr_fbm_lowpass(plan, 0, B, L.blocked_view(xb), ups, L.blocked_view(bands[0]), L.blocked_view(bands[1]),
@@ -425,7 +427,8 @@ def test_conv_mfma_bf16_plain(L, cin, cout, h, w):
     assert (got2 - ref).abs().max().item() < tol
 
 
-def test_conv_and_gates_channel_blocked_layout(L):
+@pytest.mark.parametrize('cb', [8, 32])
+def test_conv_and_gates_channel_blocked_layout(L, cb):
     """bf16 MFMA conv + gates with channel-blocked activations, bands and output, NHWC upsampled source."""
     lib = L.lib()
     B, h, w, cin, cout = 2, 12, 20, 64, 64
@@ -436,7 +439,7 @@ def test_conv_and_gates_channel_blocked_layout(L):
     sd = gp.fdconv_params(cin, cout, 9)
     lp, _ = make_lp(L, sd, cin, cout, torch.bfloat16, keep)
     xn = nhwc(x, torch.bfloat16)
-    bb = [blocked(b_, torch.bfloat16) for b_ in bands]
+    bb = [blocked(b_, torch.bfloat16, cb) for b_ in bands]
     cc = L.Concat()
     cc.nseg, cc.ups, cc.bands = 1, 1, 1
     cc.x[0] = L.view(xn)
@@ -453,11 +456,11 @@ def test_conv_and_gates_channel_blocked_layout(L):
     wt = bf(rnd((B, cout, cin, 3, 3), 115, 0.1))
     wd = dev(wt.permute(0, 3, 4, 1, 2).reshape(B, 9, cout, cin)).contiguous().to(torch.bfloat16)
     r1 = bf(rnd((B, cout, H, W), 116))
-    r1b = blocked(r1, torch.bfloat16)
+    r1b = blocked(r1, torch.bfloat16, cb)
     ep = L.Epilogue()
     ep.lrelu = 1
     ep.r1, ep.s1 = L.blocked_view(r1b), 0.2
-    out = torch.full((B, cout // 8, H, W, 8), float('nan'), device='cuda:0', dtype=torch.bfloat16)
+    out = torch.full((B, cout // cb, H, W, cb), float('nan'), device='cuda:0', dtype=torch.bfloat16)
     L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, cout, C.byref(ep),
                            L.blocked_view(out), st(L)))
     torch.cuda.synchronize()

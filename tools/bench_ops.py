@@ -48,32 +48,74 @@ def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0):
           (Cc, H, W, B, blocked, t * 1e6, 8.0, px * 8 / t / 1e12))
 
 
-def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1):
+def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
     segs = [64] + [32] * ((cin - 64) // 32)
-    xs = [torch.rand(B, H, W, c, device=dev).to(torch.bfloat16) for c in segs]
-    bs = [[torch.rand(B, H, W, c, device=dev).to(torch.bfloat16) for _ in range(3)] for c in segs]
+    shp = (lambda c: (B, c // 8, H, W, 8)) if blocked else (lambda c: (B, H, W, c))
+    mk = L.blocked_view if blocked else L.view
+    xs = [torch.rand(shp(c), device=dev).to(torch.bfloat16) for c in segs]
+    bs = [[torch.rand(shp(c), device=dev).to(torch.bfloat16) for _ in range(3)] for c in segs]
     gates = torch.rand(B, H, W, 4, device=dev) * 2
     wd = (torch.randn(B, 9, cout, cin, device=dev) * 0.05).to(torch.bfloat16)
-    out = torch.empty(B, H, W, cout, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(shp(cout), device=dev, dtype=torch.bfloat16)
     cc = L.Concat()
     cc.nseg, cc.bands = len(segs), bands
     for i in range(len(segs)):
-        cc.x[i] = L.view(xs[i])
-        cc.l2[i], cc.l4[i], cc.l8[i] = [L.view(t) for t in bs[i]]
+        cc.x[i] = mk(xs[i])
+        cc.l2[i], cc.l4[i], cc.l8[i] = [mk(t) for t in bs[i]]
     ep = L.Epilogue()
     ep.lrelu = 1
 
     def run():
         L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, cout, C.byref(ep),
-                               L.view(out), st))
+                               mk(out), st))
     t = timeit(run, reps)
     px = B * H * W
     byts = px * ((4 if bands else 1) * cin * 2 + (16 if bands else 0) + cout * 2)
-    print('conv %d->%d %dx%d B=%d bands=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic' %
-          (cin, cout, H, W, B, bands, t * 1e6, 2.0 * 9 * cin * cout * px / t / 1e12, byts / t / 1e12))
+    print('conv %d->%d %dx%d B=%d bands=%d blocked=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic' %
+          (cin, cout, H, W, B, bands, blocked, t * 1e6, 2.0 * 9 * cin * cout * px / t / 1e12, byts / t / 1e12))
+
+
+def gates(cin=160, H=512, W=512, B=16, reps=10, blocked=0):
+    segs = [64] + [32] * ((cin - 64) // 32)
+    shp = (lambda c: (B, c // 8, H, W, 8)) if blocked else (lambda c: (B, H, W, c))
+    mk = L.blocked_view if blocked else L.view
+    xs = [torch.rand(shp(c), device=dev).to(torch.bfloat16) for c in segs]
+    cc = L.Concat()
+    cc.nseg = len(segs)
+    for i in range(len(segs)):
+        cc.x[i] = mk(xs[i])
+    lp = L.LayerParams()
+    lp.cin, lp.cout, lp.active = cin, 32, 1
+    gw = [torch.randn(cin, 9, device=dev) * 0.05 for _ in range(3)]
+    gb = [torch.zeros(1, device=dev) for _ in range(3)]
+    for k in range(3):
+        lp.gate_w[k], lp.gate_b[k] = gw[k].data_ptr(), gb[k].data_ptr()
+    out = torch.empty(B, H, W, 4, device=dev)
+
+    def run():
+        L.check(lib.sr_fbm_gates(1, B, H, W, C.byref(cc), C.byref(lp), out.data_ptr(), st))
+    t = timeit(run, reps)
+    px = B * H * W
+    print('gates cin=%d %dx%d B=%d blocked=%d: %.1f us  %.2f TB/s algorithmic' % (cin, H, W, B, blocked, t * 1e6, px * (cin * 2 + 16) / t / 1e12))
+
+
+def all_ops():
+    for cin, cout in ((64, 32), (96, 32), (128, 32), (160, 32), (192, 64)):
+        conv(cin, cout)
+    conv(192, 64, bands=0)
+    for cin, cout in ((64, 32), (160, 32), (192, 64)):
+        conv(cin, cout, blocked=1)
+    for cin in (64, 128, 192):
+        gates(cin)
+    gates(64, blocked=1)
+    gates(192, blocked=1)
+    lowpass(32)
+    lowpass(32, blocked=1)
+    lowpass(64)
+    lowpass(64, 2048, 2048, 1, 5, 1)
 
 
 if __name__ == '__main__':
     op = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {'lowpass': lowpass, 'conv': conv}[op](*args)
+    {'lowpass': lowpass, 'conv': conv, 'gates': gates, 'all': all_ops}[op](*args)
