@@ -183,6 +183,20 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
     const bf16_t* b4 = BANDS ? (const bf16_t*)v4.p + (long)b * v4.bs : nullptr;
     const bf16_t* b8 = BANDS ? (const bf16_t*)v8.p + (long)b * v8.bs : nullptr;
     const float4* gb = (const float4*)gates + (long)b * H * W;
+    // ---- weight slab: rows (tap, o) x 32 channels (L2-resident); issued first so that its latency hides behind
+    // the pixel rounds, written to LDS last
+    constexpr int WITEMS = 9 * MT * 32 * 4;
+    constexpr int WG = (WITEMS + 255) / 256;
+    uint4 wv[WG];
+#pragma unroll
+    for (int g = 0; g < WG; ++g) {
+        const int it = ltid + g * 256;
+        const int chunk = it & 3, row = it >> 2;
+        const int tap = row / (MT * 32), o = row - tap * (MT * 32);
+        const int tapc = min(tap, 8), oc = min(o_blk + o, cout - 1);
+        wv[g] = *(const uint4*)(wb + ((long)tapc * cout + oc) * cin + cur.kc + chunk * 8);
+        if (o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
+    }
     for (int it0 = ltid; it0 < NPIX * 4; it0 += 256 * G) {
         uint4 vx_[G], a2[G], a4[G], a8[G];
         float4 gg[G];
@@ -225,19 +239,7 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
             if (dst[g] >= 0) *(uint4*)(lds_px + dst[g]) = v;
         }
     }
-    // ---- weight slab: rows (tap, o) x 32 channels (L2-resident) -------------------------------------------
-    constexpr int WITEMS = 9 * MT * 32 * 4;
-    constexpr int WG = (WITEMS + 255) / 256;
-    uint4 wv[WG];
-#pragma unroll
-    for (int g = 0; g < WG; ++g) {
-        const int it = ltid + g * 256;
-        const int chunk = it & 3, row = it >> 2;
-        const int tap = row / (MT * 32), o = row - tap * (MT * 32);
-        const int tapc = min(tap, 8), oc = min(o_blk + o, cout - 1);
-        wv[g] = *(const uint4*)(wb + ((long)tapc * cout + oc) * cin + cur.kc + chunk * 8);
-        if (o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    // ---- weight slab (fetched first, see above) ---------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < WG; ++g) {
         const int it = ltid + g * 256;
@@ -339,9 +341,14 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         for (int c = 0; c < nchunks; ++c) {
             const char* cur_px = lds + (step & 1) * STAGE;
             const char* cur_w = cur_px + STAGE_PX;
+            // dy stays a real loop: fully unrolled, the 36 swizzled pixel addresses are hoisted into registers and
+            // (with 128 accumulators at MT = 2) spill; reloading spills inside this loop costs more than the few
+            // address instructions per iteration
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap % 3;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int tap = dy * 3 + dx;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const int chunk = kk * 2 + hk;

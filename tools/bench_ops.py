@@ -32,7 +32,7 @@ def timeit(fn, reps):
 def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0):
     plan = C.c_void_p()
     L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
-    shape = (B, Cc // 8, H, W, 8) if blocked else (B, H, W, Cc)
+    shape = (B, Cc // blocked, H, W, blocked) if blocked else (B, H, W, Cc)
     mk = L.blocked_view if blocked else L.view
     x = torch.rand(shape, device=dev).to(torch.bfloat16)
     bands = [torch.empty_like(x) for _ in range(3)]
@@ -50,7 +50,7 @@ def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0):
 
 def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
     segs = [64] + [32] * ((cin - 64) // 32)
-    shp = (lambda c: (B, c // 8, H, W, 8)) if blocked else (lambda c: (B, H, W, c))
+    shp = (lambda c: (B, c // blocked, H, W, blocked)) if blocked else (lambda c: (B, H, W, c))
     mk = L.blocked_view if blocked else L.view
     xs = [torch.rand(shp(c), device=dev).to(torch.bfloat16) for c in segs]
     bs = [[torch.rand(shp(c), device=dev).to(torch.bfloat16) for _ in range(3)] for c in segs]
@@ -77,7 +77,7 @@ def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
 
 def gates(cin=160, H=512, W=512, B=16, reps=10, blocked=0):
     segs = [64] + [32] * ((cin - 64) // 32)
-    shp = (lambda c: (B, c // 8, H, W, 8)) if blocked else (lambda c: (B, H, W, c))
+    shp = (lambda c: (B, c // blocked, H, W, blocked)) if blocked else (lambda c: (B, H, W, c))
     mk = L.blocked_view if blocked else L.view
     xs = [torch.rand(shp(c), device=dev).to(torch.bfloat16) for c in segs]
     cc = L.Concat()
@@ -104,15 +104,15 @@ def all_ops():
         conv(cin, cout)
     conv(192, 64, bands=0)
     for cin, cout in ((64, 32), (160, 32), (192, 64)):
-        conv(cin, cout, blocked=1)
+        conv(cin, cout, blocked=32)
     for cin in (64, 128, 192):
         gates(cin)
-    gates(64, blocked=1)
-    gates(192, blocked=1)
+    gates(64, blocked=32)
+    gates(192, blocked=32)
     lowpass(32)
-    lowpass(32, blocked=1)
+    lowpass(64, blocked=32)
     lowpass(64)
-    lowpass(64, 2048, 2048, 1, 5, 1)
+    lowpass(64, 2048, 2048, 1, 5, 8)
 
 
 if __name__ == '__main__':
