@@ -75,6 +75,7 @@ _SIGS = {
     'sr_rrdbnet_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]),
     'sr_debug_force_generic_conv': (None, [C.c_int]),
     'sr_debug_force_generic_fft': (None, [C.c_int]),
+    'sr_debug_force_fft_lowpass': (None, [C.c_int]),
     'sr_debug_force_generic_gates': (None, [C.c_int]),
 }
 

@@ -133,6 +133,9 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 #define SR_NOT_ELIGIBLE (-100)
 int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
                      int pooled_ld, void* ws, hipStream_t st);
+// bf16 only: the three passes as real-basis DFT GEMMs on the matrix cores (SR_NOT_ELIGIBLE otherwise)
+int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
+                     int pooled_ld, void* ws, hipStream_t st);
 int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_layer_params& lp, float* gates,
                      hipStream_t st);
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
 }
 
 int g_force_generic_fft = 0;  // test hook
+int g_force_fft_lowpass = 1;  // the MFMA (DFT-as-GEMM) path of fbm_mfma.hip is opt-in: correct, not yet faster than the FFT
 
 static Radix make_radix(const int* r, int nf) {
     Radix x{};
@@ -265,6 +266,10 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     const int H = pl->H, W = pl->W, C = x.C;
     const int PT = (C + 1) / 2;
     if (ws_bytes < sr_fbm_workspace_bytes(pl, B, C)) return SR_ERR_WORKSPACE;
+    if (!g_force_generic_fft && !g_force_fft_lowpass) {
+        const int rc = fbm_lowpass_mfma(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st);
+        if (rc != SR_NOT_ELIGIBLE) return rc;
+    }
     if (!g_force_generic_fft) {
         const int rc = fbm_lowpass_pow2(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st);
         if (rc != SR_NOT_ELIGIBLE) return rc;
@@ -308,6 +313,7 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 using namespace sr;
 
 extern "C" void sr_debug_force_generic_fft(int on) { sr::g_force_generic_fft = on; }
+extern "C" void sr_debug_force_fft_lowpass(int on) { sr::g_force_fft_lowpass = on; }
 
 extern "C" int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host) {
     SR_REQUIRE(H > 0 && W > 0 && rows_host && cols_host);
@@ -407,6 +413,8 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
     pl->cols4 = (int*)(dev + o_c4);
     pl->cols8 = (int*)(dev + o_c8);
     pl->rowmask = (float*)(dev + o_rm);
+    const int mrc = fbm_mfma_plan_build(pl, rows.data());
+    if (mrc != SR_OK) { hipFree(dev); free(pl); return mrc; }
     *out = pl;
     return SR_OK;
 }
@@ -414,6 +422,7 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
 extern "C" void sr_fbm_plan_destroy(sr_fbm_plan* pl) {
     if (!pl) return;
     if (pl->dev_block) (void)hipFree(pl->dev_block);
+    fbm_mfma_plan_free(pl);
     free(pl);
 }
 

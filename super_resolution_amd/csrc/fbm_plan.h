@@ -18,5 +18,23 @@ struct sr_fbm_plan {
     void* dev_block;       // one allocation backing all of the above
     int half[3];           // kept columns of mask k are [0,half) u (W-half, W) when contiguous != 0
     int contiguous;
+    // ---- real-basis tables of the MFMA path (fbm_mfma.hip); mf_ok == 0 when the shape / masks are not covered ----
+    int mf_ok;
+    int mf_jw;             // x-basis functions kept by mask k=2 (DC, dummy, then cos c / sin c pairs) = 2 * half[0]
+    int mf_nw[3];          // prefix of them kept by mask k
+    int mf_nh;             // y-basis functions with non-zero weight in mask k=2 (same ordering)
+    int mf_nhk[3];         // prefix with non-zero symmetric weight per mask
+    int mf_ld_qw, mf_ld_b2[3];
+    void* mf_block;        // one device allocation: the four tables below (fp16)
+    void* mf_qwt;          // [pad32(jw)][W]      q_j[w]           rows forward
+    void* mf_qw;           // [W][pad16(jw)]      q_j[w]           rows inverse (band k uses the first nw[k] columns)
+    void* mf_pht;          // [pad32(nh)][H]      p_n[h]           columns forward
+    void* mf_b2[3];        // [H][pad16(nhk)+16]  16 s_n p_n[h'] ++ 16 d_f p(h') for the asymmetric rows of mask k
+    int mf_asym0[3], mf_nasym[3];  // first asymmetric y-frequency of mask k and how many (<= 8)
 };
+
+namespace sr {
+int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows /*[3][H]*/);  // SR_OK also when not eligible
+void fbm_mfma_plan_free(sr_fbm_plan* pl);
+}
 

@@ -164,6 +164,50 @@ def test_fbm_lowpass_pow2_upsampled_bf16(L):
     assert (pooled - xu.mean(dim=(2, 3))).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('shape,ups,cb', [((2, 32, 64, 96), 0, 0), ((1, 64, 128, 64), 0, 32), ((1, 32, 512, 128), 0, 32),
+                                          ((1, 32, 96, 160), 0, 0), ((2, 64, 32, 48), 1, 32), ((1, 32, 256, 512), 0, 32)])
+def test_fbm_lowpass_mfma_bf16(L, shape, ups, cb):
+    """The opt-in DFT-as-GEMM path (fp16 MFMA, fbm_mfma.hip) for bf16 planes of 32-channel groups: against the oracle
+    (asymmetric row masks at H = 96, 128, 256, 512 included) and against the default FFT path on the same input."""
+    lib = L.lib()
+    x = bf(torch.from_numpy(gp.signed_input(shape, 23)))
+    B, Cc, H, W = x.shape
+    Ho, Wo = H << ups, W << ups
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(Ho, Wo, C.byref(plan)))
+    if cb:
+        xd, mk = blocked(x, torch.bfloat16, cb), L.blocked_view
+        mkb = lambda: torch.full((B, Cc // cb, Ho, Wo, cb), float('nan'), device='cuda:0', dtype=torch.bfloat16)
+        back = unblocked
+    else:
+        xd, mk = nhwc(x, torch.bfloat16), L.view
+        mkb = lambda: torch.full((B, Ho, Wo, Cc), float('nan'), device='cuda:0', dtype=torch.bfloat16)
+        back = nchw
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+    res = []
+    for force_fft in (0, 1):
+        bands = [mkb() for _ in range(3)]
+        pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
+        lib.sr_debug_force_fft_lowpass(force_fft)
+        try:
+            L.check(lib.sr_fbm_lowpass(plan, 1, B, mk(xd), ups, mk(bands[0]), mk(bands[1]), mk(bands[2]), pooled.data_ptr(), Cc,
+                                       ws.data_ptr(), ws.numel(), st(L)))
+            torch.cuda.synchronize()
+        finally:
+            lib.sr_debug_force_fft_lowpass(1)
+        res.append(([back(b_) for b_ in bands], pooled.cpu()))
+    lib.sr_fbm_plan_destroy(plan)
+    xu = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    ref = fr.fbm_lowpass(xu.double()).float()
+    for k in range(3):
+        tol = 2.0 ** -8 * max(1.0, ref[k].abs().max().item())
+        assert (res[0][0][k] - ref[k]).abs().max().item() < tol, k
+        assert (res[0][0][k] - res[1][0][k]).abs().max().item() < 2 * tol, k
+        # the GEMM path must not be noisier than bf16 rounding of the result itself
+        assert (res[0][0][k] - ref[k]).pow(2).mean().sqrt().item() < 2.0 ** -9 * ref[k].pow(2).mean().sqrt().item() + 1e-6, k
+    assert (res[0][1] - xu.mean(dim=(2, 3))).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize('shape,ups,cb', [((1, 16, 64, 128), 0, 8), ((2, 8, 32, 64), 1, 8), ((1, 8, 2048, 64), 0, 8),
                                           ((1, 24, 40, 36), 0, 8), ((2, 64, 64, 128), 0, 32), ((1, 32, 32, 64), 1, 32),
                                           ((1, 64, 40, 36), 0, 32), ((1, 32, 64, 64), 0, 16)])

@@ -29,7 +29,8 @@ def timeit(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0):
+def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0, force_fft=1):
+    lib.sr_debug_force_fft_lowpass(force_fft)
     plan = C.c_void_p()
     L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
     shape = (B, Cc // blocked, H, W, blocked) if blocked else (B, H, W, Cc)
@@ -44,8 +45,9 @@ def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0):
                                    ws.data_ptr(), ws.numel(), st))
     t = timeit(run, reps)
     px = B * H * W * Cc
-    print('lowpass C=%d %dx%d B=%d blocked=%d: %.1f us  (%.2f B/px/ch algorithmic 8 -> %.2f TB/s)' %
-          (Cc, H, W, B, blocked, t * 1e6, 8.0, px * 8 / t / 1e12))
+    lib.sr_debug_force_fft_lowpass(1)
+    print('lowpass C=%d %dx%d B=%d blocked=%d fft=%d: %.1f us  (%.2f B/px/ch algorithmic 8 -> %.2f TB/s)' %
+          (Cc, H, W, B, blocked, force_fft, t * 1e6, 8.0, px * 8 / t / 1e12))
 
 
 def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
