@@ -60,6 +60,18 @@ def conv_bytes_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_G
     return tot
 
 
+def measured_conv_traffic():
+    """HBM bytes per conv launch from the committed PMC passes of this same command (profiles/*_hbm_traffic.json:
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; counters cannot be read in-process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d['per_launch']['conv']['hbm_gb_per_launch_corrected'] * 1e9, os.path.relpath(files[-1], ROOT)
+
+
 def synthetic_batch(B, H, W, device, seed=1234):
     """DL-SMLM-like wide-field frames: sparse positive blobs (Poisson emitters blurred by a PSF) + floor noise."""
     g = torch.Generator(device='cpu').manual_seed(seed)
@@ -158,6 +170,7 @@ def main():
     tflops = conv_flops_step / conv_s_step / 1e12
     conv_bytes_step = float(conv_bytes_per_lr_pixel(1, 1)) * B * H * W
     gbs = conv_bytes_step / conv_s_step / 1e9
+    traffic, traffic_src = measured_conv_traffic()
     res = {
         'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
         'value': out_mpix / (elapsed / args.steps),
@@ -177,7 +190,8 @@ def main():
                    'output_finite': finite},
         # the FDConv conv streams 4 tensors per input channel: ~70 FLOP/B, far left of the 312 FLOP/B ridge -> HBM-bound
         'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_mfma_bf16 (average over the %d conv launches of a step)' % (conv_n // args.steps),
-                     'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                     'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic,
+                     'traffic_unit': 'bytes per launch (PMC, %s)' % traffic_src,
                      'avg_launch_ms': conv_ms / max(conv_n, 1),
                      'algorithmic_gb_per_launch': conv_bytes_step / 1e9 / max(conv_n // args.steps, 1),
                      'mfma': {'achieved': tflops, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

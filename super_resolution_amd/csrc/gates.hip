@@ -2,6 +2,8 @@
 // Cin -> 3 output planes: a bandwidth-shaped kernel.  One workgroup = one 16x16 pixel tile; the
 // halo tile of a few channels is staged in LDS plane-major so that the 9-tap reads of
 // neighbouring lanes hit neighbouring banks.
+#include <algorithm>
+
 #include "common.h"
 
 namespace sr {
@@ -94,13 +96,11 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
     const int astride = cin * 2 + 16;
     const int tilesx = (W + GMW - 1) / GMW;
     const unsigned tiles = (unsigned)tilesx * ((H + GMH - 1) / GMH);
-    const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);  // (tile, sample), tile fastest, XCD-contiguous
-    const int tile = lin % tiles, b = lin / tiles;
-    const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hk = lane >> 5;
     const int Hs = H >> in.ups, Ws = W >> in.ups;
-    // stage the 27 x cin weight matrix as bf16 (rows 27..31 are zero)
+    // stage the 27 x cin weight matrix as bf16 (rows 27..31 are zero) -- once per workgroup: the kernel is persistent
+    // (staging it per 8 x 32 tile cost more than the tile itself)
     const float* wk[3] = {w0, w1, w2};
     for (int it = tid; it < 32 * cin; it += 256) {
         const int c = it % cin, row = it / cin;
@@ -108,31 +108,70 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
         if (row < 27) v = wk[row % 3][(long)c * 9 + row / 3];
         *(bf16_t*)(A + row * astride + c * 2) = f32_to_bf16(v);
     }
-    __syncthreads();
-    for (int nt = wave; nt < GNT; nt += 4) {
-        const int slot = nt * 32 + r;
-        const int py = slot / GPW, px = slot - py * GPW;
-        const int h = h0 + py - 1, w = w0p + px - 1;
-        const bool ok = slot < GSLOTS && h >= 0 && h < H && w >= 0 && w < W;
-        const long ps = (long)(h >> in.ups) * Ws + (w >> in.ups);
-        g_float16 acc;
+    // XCD-contiguous walk over (tile, sample): workgroup j lives on XCD j % 8 and strides through that XCD's range
+    const unsigned total = tiles * (unsigned)B;
+    const unsigned xj = blockIdx.x & 7u, q8 = total >> 3, r8 = total & 7u;
+    const unsigned wstart = xj * q8 + (xj < r8 ? xj : r8), wend = wstart + q8 + (xj < r8 ? 1u : 0u);
+    const unsigned wstride = (gridDim.x - xj + 7u) >> 3;
+    for (unsigned lin = wstart + (blockIdx.x >> 3); lin < wend; lin += wstride) {
+    const int tile = lin % tiles, b = lin / tiles;
+    const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
+    __syncthreads();  // weights staged / T of the previous tile consumed
+    // Two N-tiles (64 pixel slots) per wave and iteration, and all fragments of up to 64 channels of both fetched before
+    // the first product: 4-8 independent 16-byte loads per lane in flight instead of one per dependent MFMA.
+    for (int nt0 = wave * 2; nt0 < GNT; nt0 += 8) {
+        bool ok[2];
+        long ps[2];
+        int slot[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int u = 0; u < 2; ++u) {
+            slot[u] = (nt0 + u) * 32 + r;
+            const int py = slot[u] / GPW, px = slot[u] - py * GPW;
+            const int h = h0 + py - 1, w = w0p + px - 1;
+            ok[u] = nt0 + u < GNT && slot[u] < GSLOTS && h >= 0 && h < H && w >= 0 && w < W;
+            // clamped address, zeroed afterwards: no branch around the loads
+            const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+            ps[u] = (long)(hc >> in.ups) * Ws + (wc >> in.ups);
+        }
+        g_float16 acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
         int kc = 0;
         for (int s = 0; s < in.nseg; ++s) {
             const View v = in.x[s];
-            for (int cc = 0; cc < v.C; cc += 16, kc += 16) {
-                g_short8 bfrag = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) bfrag = *(const g_short8*)((const bf16_t*)v.p + voff(v, b, ps, cc + hk * 8));
-                const g_short8 afrag = *(const g_short8*)(A + r * astride + (kc + hk * 8) * 2);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+            for (int cc = 0; cc < v.C; cc += 64) {
+                g_short8 bf[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int c = min(cc + 16 * t, v.C - 16);
+                        bf[u][t] = *(const g_short8*)((const bf16_t*)v.p + voff(v, b, ps[u], c + hk * 8));
+                    }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (cc + 16 * t >= v.C) break;
+                    const g_short8 afrag = *(const g_short8*)(A + r * astride + (kc + 16 * t + hk * 8) * 2);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const g_short8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, ok[u] ? bf[u][t] : z, acc[u], 0, 0, 0);
+                    }
+                }
+                kc += min(64, v.C - cc);
             }
         }
         // acc[i] = T[row = (i&3) + 8*(i>>2) + 4*hk][slot]
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * hk;
-            if (row < 27) T[slot * GTROW + row] = acc[i];
+        for (int u = 0; u < 2; ++u) {
+            if (nt0 + u >= GNT) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * hk;
+                if (row < 27) T[slot[u] * GTROW + row] = acc[u][i];
+            }
         }
     }
     __syncthreads();
@@ -154,6 +193,7 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
         g.w = 0.f;
         ((float4*)gates)[((long)b * H + h) * W + w] = g;
     }
+    }
 }
 
 static bool gates_mfma_eligible(const Concat& in) {
@@ -174,7 +214,15 @@ int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_
         SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
         if (nblk >= (1L << 31)) return SR_ERR_ARG;
-        fbm_gates_mfma<<<dim3((unsigned)nblk), 256, lds, st>>>(
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            SR_HIP(hipGetDevice(&dev));
+            SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        const long per_cu = std::max<long>(1, std::min<long>(4, (160 * 1024) / (long)lds));
+        const unsigned grid = (unsigned)std::min<long>(nblk, per_cu * ncu);
+        fbm_gates_mfma<<<dim3(grid), 256, lds, st>>>(
             in, B, H, W, lp.gate_w[0], lp.gate_w[1], lp.gate_w[2], lp.gate_b[0], lp.gate_b[1], lp.gate_b[2], gates);
         SR_LAUNCH_CHECK();
         return SR_OK;
