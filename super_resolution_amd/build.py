@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result', '-c',
+        cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fno-signed-zeros', '-fPIC', '-Wall', '-Wno-unused-result', '-c',
                os.path.join(CSRC, s), '-o', o]
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:

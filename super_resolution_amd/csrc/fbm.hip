@@ -382,6 +382,18 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
             rmask[(k * 3 + 1) * H + r] = bneg;
             rmask[(k * 3 + 2) * H + r] = 0.5f * (a + bneg);
         }
+    {   // first-pass operand ranges of the pruned inverse column transform (same radix choice as fbm_fast.hip)
+        const int r0 = (H % 8 == 0 && H != 16) ? 8 : (H % 4 == 0 ? 4 : 2), nr0 = H / r0;
+        for (int kv = 0; kv < 9; ++kv) {
+            int m = 0;
+            for (int t = 0; t < r0 && H % r0 == 0; ++t) {
+                bool zero = true;
+                for (int r = t * nr0; r < (t + 1) * nr0; ++r) zero &= rmask[(size_t)kv * H + r] == 0.f;
+                if (zero) m |= 1 << t;
+            }
+            pl->row_zmask[kv] = m;
+        }
+    }
     std::vector<float2> tww(W), twh(H);
     for (int j = 0; j < W; ++j) tww[j] = make_float2((float)cos(-2.0 * M_PI * j / W), (float)sin(-2.0 * M_PI * j / W));
     for (int j = 0; j < H; ++j) twh[j] = make_float2((float)cos(-2.0 * M_PI * j / H), (float)sin(-2.0 * M_PI * j / H));

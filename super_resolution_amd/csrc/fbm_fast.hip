@@ -12,6 +12,8 @@
 //   rows_inv : reads the sparse kept columns (zero elsewhere), writes the low-pass rows in the
 //              activation dtype.
 // Kept columns are the two contiguous runs [0, half) and (N - half, N) of the box masks.
+#include <type_traits>
+
 #include "common.h"
 #include "fbm_plan.h"
 
@@ -104,7 +106,10 @@ __device__ __forceinline__ int lds_idx(int idx, int p) {
 }
 
 // One Stockham pass.  load(idx, p, q, t) / store(idx, p, v) address point idx of signal p.
-template <int N, int P, int R, int NS, bool INV, bool BLK, bool LOAD_LDS, bool STORE_LDS, typename LoadF, typename StoreF>
+// ZM: bit t set = operand t of every butterfly of this (first) pass is zero (a masked-out range of the spectrum); the
+// load is dropped and, with -fno-signed-zeros, so is every butterfly operation it feeds.
+// OZ: bit u set = output u of every butterfly of this (last) pass is never used; it is neither stored nor computed.
+template <int N, int P, int R, int NS, bool INV, bool BLK, bool LOAD_LDS, bool STORE_LDS, int ZM, int OZ, typename LoadF, typename StoreF>
 __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load, StoreF store) {
     constexpr int NR = N / R;
     constexpr int NB = NR * P;
@@ -120,7 +125,7 @@ __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load,
         item_to_pj<P, NR, BLK>(i, p, j);
         const int k = j % NS;
 #pragma unroll
-        for (int t = 0; t < R; ++t) v[q][t] = load(j + t * NR, p, q, t);
+        for (int t = 0; t < R; ++t) v[q][t] = ((ZM >> t) & 1) ? make_float2(0.f, 0.f) : load(j + t * NR, p, q, t);
         if (NS > 1) {
 #pragma unroll
             for (int t = 1; t < R; ++t) {
@@ -141,14 +146,15 @@ __device__ __forceinline__ void pass(const float2* __restrict__ twl, LoadF load,
         const int k = j % NS;
         const int base = (j / NS) * NS * R + k;
 #pragma unroll
-        for (int u = 0; u < R; ++u) store(base + u * NS, p, v[q][u]);
+        for (int u = 0; u < R; ++u)
+            if (!((OZ >> u) & 1)) store(base + u * NS, p, v[q][u]);
     }
 }
 
 // All passes of a length-N transform: first pass loads through `lf`, last pass stores through `sl`,
 // everything in between lives in `buf` (N x P complex, in place).
 // LAST_LDS: the caller's `sl` writes into `buf` (needs the read/write barrier).
-template <int N, int P, bool INV, bool BLK, int NS, bool LAST_LDS, typename LoadFirst, typename StoreLast>
+template <int N, int P, bool INV, bool BLK, int NS, bool LAST_LDS, int ZM = 0, int OZ = 0, typename LoadFirst, typename StoreLast>
 __device__ __forceinline__ void fft(float2* __restrict__ buf, const float2* __restrict__ twl, LoadFirst lf, StoreLast sl) {
     constexpr int M = N / NS;
     constexpr int R = pick_radix(M);
@@ -156,14 +162,14 @@ __device__ __forceinline__ void fft(float2* __restrict__ buf, const float2* __re
     auto lds_load = [&](int idx, int p, int, int) { return buf[lds_idx<N, P, BLK>(idx, p)]; };
     auto lds_store = [&](int idx, int p, float2 v) { buf[lds_idx<N, P, BLK>(idx, p)] = v; };
     if constexpr (first && last)
-        pass<N, P, R, NS, INV, BLK, false, true>(twl, lf, sl);
+        pass<N, P, R, NS, INV, BLK, false, true, ZM, OZ>(twl, lf, sl);
     else if constexpr (first)
-        pass<N, P, R, NS, INV, BLK, false, true>(twl, lf, lds_store);
+        pass<N, P, R, NS, INV, BLK, false, true, ZM, 0>(twl, lf, lds_store);
     else if constexpr (last)
-        pass<N, P, R, NS, INV, BLK, true, LAST_LDS>(twl, lds_load, sl);
+        pass<N, P, R, NS, INV, BLK, true, LAST_LDS, 0, OZ>(twl, lds_load, sl);
     else
-        pass<N, P, R, NS, INV, BLK, true, true>(twl, lds_load, lds_store);
-    if constexpr (!last) fft<N, P, INV, BLK, NS * R, LAST_LDS>(buf, twl, lf, sl);
+        pass<N, P, R, NS, INV, BLK, true, true, 0, 0>(twl, lds_load, lds_store);
+    if constexpr (!last) fft<N, P, INV, BLK, NS * R, LAST_LDS, 0, OZ>(buf, twl, lf, sl);
 }
 
 extern __shared__ __attribute__((aligned(16))) char smem_fast[];
@@ -211,8 +217,31 @@ __device__ __forceinline__ unsigned y_off(const Inter& it, int gp, int h, int po
     return ((((unsigned)(gp >> it.QL) * H + h) * nk + pos) << it.QL) + (gp & (it.Q - 1));
 }
 
+// Bit t of the result: first-pass operand range [t * N/R, (t + 1) * N/R) holds no kept index of [0, a) u (N - a, N).
+template <int N>
+__host__ __device__ inline int zero_mask(int a) {
+    constexpr int R0 = first_radix(N), NR0 = N / R0;
+    int m = 0;
+#pragma unroll
+    for (int t = 0; t < R0; ++t)
+        if (t * NR0 >= a && (t + 1) * NR0 - 1 <= N - a) m |= 1 << t;
+    return m;
+}
+// The kernels below take the zero masks of the three bands as template arguments (PZ = true: the standard
+// {0x3c, 0x3c, 0x7e} of radix-8 first passes -- the middle 4 / 4 / 6 eighths of the spectrum are masked out); the host
+// picks the instance from the plan.  One specialised body per band keeps the code inside the instruction cache
+// (dispatching among several bodies per band at run time did not).
+template <bool PZ>
+constexpr int band_zm(int k) { return PZ ? (k == 2 ? 0x7e : 0x3c) : 0; }
+// Radix of the last pass, and the mask of its outputs that fall into the middle half [N/4, 3N/4) of the spectrum, which
+// no band keeps when PZ holds (forward transforms neither compute nor store them).
+constexpr int last_radix(int n) { return pick_radix(n) == n ? n : last_radix(n / pick_radix(n)); }
+template <int N, bool PZ>
+constexpr int fwd_oz() { return !PZ ? 0 : (last_radix(N) == 8 ? 0x3c : (last_radix(N) == 4 ? 0x6 : 0)); }
+
+
 // ---- rows forward -------------------------------------------------------------------------
-template <typename T, int N, int P, bool BLK>
+template <typename T, int N, int P, bool BLK, bool PZ>
 __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, float2* __restrict__ t1) {
     float2* buf = (float2*)smem_fast;
@@ -230,11 +259,11 @@ __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int 
         const int pos = kept_pos<N>(idx, a2);
         if (pos >= 0 && p0 + p < PT) t1b[t1_off(im, p0 + p, pos, h, n2, H)] = v;
     };
-    fft<N, P, false, BLK, 1, false>(buf, twl, lf, sl);
+    fft<N, P, false, BLK, 1, false, 0, fwd_oz<N, PZ>()>(buf, twl, lf, sl);
 }
 
 // ---- columns: forward, mask, inverse x3 ------------------------------------------------------
-template <int N, int P, bool BLK>
+template <int N, int P, bool BLK, bool PZ>
 __global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
                                                 int a8, const float* __restrict__ rowmask,
                                                 const float2* __restrict__ t1, float2* __restrict__ y2,
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const f
     };
     auto s_lds = [&](int r, int p, float2 v) { buf[lds_idx<N, P, BLK>(r, p)] = v; };
     // forward: the last pass stores back into LDS
-    fft<N, P, false, BLK, 1, true>(buf, twl, lf, s_lds);
+    fft<N, P, false, BLK, 1, true, 0, fwd_oz<N, PZ>()>(buf, twl, lf, s_lds);
     __syncthreads();
     if (pooled && idx == 0 && threadIdx.x < P && p0 + threadIdx.x < PT) {
         const int c = 2 * (p0 + threadIdx.x);
@@ -280,12 +309,12 @@ __global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const f
     const int variant = (col == 0 || 2 * col == W) ? 2 : (2 * col < W ? 0 : 1);
     const int ak[3] = {a2, a4, a8};
     float2* ys[3] = {y2, y4, y8};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    auto band = [&](auto kc) {  // k as a compile-time constant: it selects the pruned first pass
+        constexpr int k = decltype(kc)::value;
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const int pos = col < a ? col : (col > W - a ? col - (W - nk) : -1);
-        if (pos < 0) continue;  // block-uniform
+        if (pos < 0) return;  // block-uniform
         const float* rm = rowmask + (k * 3 + variant) * H;
         // the first inverse pass takes the saved operands, scaled by the row mask
         auto lm = [&](int r, int, int q, int t) {
@@ -296,12 +325,15 @@ __global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const f
         auto sl = [&](int h, int p, float2 v) {
             if (p0 + p < PT) y[y_off(im, p0 + p, h, pos, nk, H)] = v;
         };
-        fft<N, P, true, BLK, 1, false>(buf, twl, lm, sl);
-    }
+        fft<N, P, true, BLK, 1, false, band_zm<PZ>(k)>(buf, twl, lm, sl);
+    };
+    band(std::integral_constant<int, 0>{});
+    band(std::integral_constant<int, 1>{});
+    band(std::integral_constant<int, 2>{});
 }
 
 // ---- rows inverse -------------------------------------------------------------------------
-template <typename T, int N, int P, bool BLK>
+template <typename T, int N, int P, bool BLK, bool PZ>
 __global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, int a4, int a8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
@@ -315,8 +347,8 @@ __global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, i
     const float2* ys[3] = {y2, y4, y8};
     const View outs[3] = {l2, l4, l8};
     const unsigned rowpix = (unsigned)h * N;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    auto band = [&](auto kc) {  // k as a compile-time constant: it selects the pruned first pass
+        constexpr int k = decltype(kc)::value;
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
@@ -329,8 +361,11 @@ __global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, i
         auto sl = [&](int w, int p, float2 v) {
             if (p0 + p < PT) Pair<T>::st(ob + voff32(o, rowpix + w, 2 * (p0 + p)), make_float2(v.x * norm, v.y * norm));
         };
-        fft<N, P, true, BLK, 1, false>(buf, twl, lf, sl);
-    }
+        fft<N, P, true, BLK, 1, false, band_zm<PZ>(k)>(buf, twl, lf, sl);
+    };
+    band(std::integral_constant<int, 0>{});
+    band(std::integral_constant<int, 1>{});
+    band(std::integral_constant<int, 2>{});
 }
 
 // ---- host dispatch ---------------------------------------------------------------------------
@@ -342,8 +377,15 @@ static int launch_rows_fwd(View x, int ups, int B, int H, int PT, Inter im, cons
                            hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
-    SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rows_fwd<T, N, P, BLK><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, im, pl->tw_w, pl->half[0], t1);
+    // kept columns of the widest mask inside the outer quarters: the last pass skips the middle half of its outputs
+    const bool pz = pl->half[0] <= N / 4 && fwd_oz<N, true>() != 0;
+    if (pz) {
+        SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P, BLK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        rows_fwd<T, N, P, BLK, true><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, im, pl->tw_w, pl->half[0], t1);
+    } else {
+        SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P, BLK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        rows_fwd<T, N, P, BLK, false><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, im, pl->tw_w, pl->half[0], t1);
+    }
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -353,9 +395,18 @@ static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inte
                            const float2* y2, const float2* y4, const float2* y8, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
-    SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rows_inv<T, N, P, BLK><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
-                                                                        pl->half[1], pl->half[2], y2, y4, y8);
+    // standard masks along W: operand ranges 2..5 (k = 2, 4) and 1..6 (k = 8) of a radix-8 first pass are empty
+    const bool pz = first_radix(N) == 8 && (zero_mask<N>(pl->half[0]) & 0x3c) == 0x3c && (zero_mask<N>(pl->half[1]) & 0x3c) == 0x3c &&
+                    (zero_mask<N>(pl->half[2]) & 0x7e) == 0x7e;
+    if (pz) {
+        SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P, BLK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        rows_inv<T, N, P, BLK, true><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
+                                                                            pl->half[1], pl->half[2], y2, y4, y8);
+    } else {
+        SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P, BLK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        rows_inv<T, N, P, BLK, false><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
+                                                                            pl->half[1], pl->half[2], y2, y4, y8);
+    }
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -365,10 +416,19 @@ static int launch_cols(int B, int W, int PT, int C, Inter im, const sr_fbm_plan*
                        float2* y4, float2* y8, float* pooled, int pooled_ld, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
-    SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    cols<N, P, BLK><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1],
-                                                                         pl->half[2], pl->rowmask, t1, y2, y4, y8, pooled,
-                                                                         pooled_ld, C);
+    bool pz = first_radix(N) == 8;  // every variant of every row mask must leave the standard ranges empty
+    for (int kv = 0; kv < 9; ++kv) pz = pz && (pl->row_zmask[kv] & (kv >= 6 ? 0x7e : 0x3c)) == (kv >= 6 ? 0x7e : 0x3c);
+    if (pz) {
+        SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cols<N, P, BLK, true><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1],
+                                                                             pl->half[2], pl->rowmask, t1, y2, y4, y8, pooled,
+                                                                             pooled_ld, C);
+    } else {
+        SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cols<N, P, BLK, false><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1],
+                                                                             pl->half[2], pl->rowmask, t1, y2, y4, y8, pooled,
+                                                                             pooled_ld, C);
+    }
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

@@ -18,6 +18,7 @@ struct sr_fbm_plan {
     void* dev_block;       // one allocation backing all of the above
     int half[3];           // kept columns of mask k are [0,half) u (W-half, W) when contiguous != 0
     int contiguous;
+    int row_zmask[9];      // [mask k][variant]: bit t set = rows [t*H/R0, (t+1)*H/R0) of that row mask are all zero (R0 = first radix of H)
     // ---- real-basis tables of the MFMA path (fbm_mfma.hip); mf_ok == 0 when the shape / masks are not covered ----
     int mf_ok;
     int mf_jw;             // x-basis functions kept by mask k=2 (DC, dummy, then cos c / sin c pairs) = 2 * half[0]
