@@ -368,44 +368,63 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             __syncthreads();  // stage `step` consumed; stage `step + 1` is full
             ++step;
         }
-        // ---- epilogue: lane holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each tile ----
+        // ---- epilogue: lane (r, hk) holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each 32-channel tile.
+        // v_permlane32_swap between lanes r and r + 32 regroups them into 16 consecutive channels per lane (low lanes
+        // 0..15, high lanes 16..31), so residuals are read and results written as 16-byte pieces, two per lane,
+        // instead of four 8-byte ones (the 8-byte version took 6 us per tile on its own).
         const int w = w0 + r;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int h = h0 + wave * 4 + n;
-            if (h >= H || w >= W) continue;
-            const long pix = (long)h * W + w;
+            const bool inside = h < H && w < W;
+            const long pix = (long)min(h, H - 1) * W + min(w, W - 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
+                float y[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = o_blk + m * 32 + q * 8 + hk * 4;
-                    if (o >= cout) continue;
-                    float y[4];
+                for (int j = 0; j < 4; ++j) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][n][j]), __float_as_uint(acc[m][n][8 + j]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][n][4 + j]), __float_as_uint(acc[m][n][12 + j]), false, false);
+                    y[j] = __uint_as_float(s0[0]);
+                    y[4 + j] = __uint_as_float(s0[1]);
+                    y[8 + j] = __uint_as_float(s1[0]);
+                    y[12 + j] = __uint_as_float(s1[1]);
+                }
+                const int cb = o_blk + m * 32 + hk * 16;
+                if (!inside || cb >= cout) continue;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = acc[m][n][q * 4 + j] + (ep.bias ? ep.bias[o + j] : 0.f);
-                    if (ep.lrelu) {
+                for (int j = 0; j < 16; ++j) y[j] += ep.bias ? ep.bias[cb + j] : 0.f;
+                if (ep.lrelu) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = lrelu02(y[j]);
-                    }
+                    for (int j = 0; j < 16; ++j) y[j] = lrelu02(y[j]);
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float* yh = y + 8 * half;
                     if (ep.r1.p) {
-                        const uint2 rr = *(const uint2*)((const bf16_t*)ep.r1.p + voff(ep.r1, b, pix, o));
-                        y[0] = y[0] * ep.s1 + lo_f(rr.x);
-                        y[1] = y[1] * ep.s1 + hi_f(rr.x);
-                        y[2] = y[2] * ep.s1 + lo_f(rr.y);
-                        y[3] = y[3] * ep.s1 + hi_f(rr.y);
+                        const uint4 rr = *(const uint4*)((const bf16_t*)ep.r1.p + voff(ep.r1, b, pix, cb + 8 * half));
+                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            yh[2 * j] = yh[2 * j] * ep.s1 + lo_f(rw[j]);
+                            yh[2 * j + 1] = yh[2 * j + 1] * ep.s1 + hi_f(rw[j]);
+                        }
                     }
                     if (ep.r2.p) {
-                        const uint2 rr = *(const uint2*)((const bf16_t*)ep.r2.p + voff(ep.r2, b, pix, o));
-                        y[0] = y[0] * ep.s2 + lo_f(rr.x);
-                        y[1] = y[1] * ep.s2 + hi_f(rr.x);
-                        y[2] = y[2] * ep.s2 + lo_f(rr.y);
-                        y[3] = y[3] * ep.s2 + hi_f(rr.y);
+                        const uint4 rr = *(const uint4*)((const bf16_t*)ep.r2.p + voff(ep.r2, b, pix, cb + 8 * half));
+                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            yh[2 * j] = yh[2 * j] * ep.s2 + lo_f(rw[j]);
+                            yh[2 * j + 1] = yh[2 * j + 1] * ep.s2 + hi_f(rw[j]);
+                        }
                     }
-                    uint2 st;
-                    st.x = pack2(y[0], y[1]);
-                    st.y = pack2(y[2], y[3]);
-                    *(uint2*)((bf16_t*)out.p + voff(out, b, pix, o)) = st;
+                    uint4 st;
+                    st.x = pack2(yh[0], yh[1]);
+                    st.y = pack2(yh[2], yh[3]);
+                    st.z = pack2(yh[4], yh[5]);
+                    st.w = pack2(yh[6], yh[7]);
+                    *(uint4*)((bf16_t*)out.p + voff(out, b, pix, cb + 8 * half)) = st;
                 }
             }
         }
@@ -424,9 +443,9 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
                 if (!view_vec_ok(*v, 8) || v->bs >= (1L << 31)) return false;
         }
     }
-    if (!view_vec_ok(out, 4)) return false;
-    if (ep.r1.p && !view_vec_ok(ep.r1, 4)) return false;
-    if (ep.r2.p && !view_vec_ok(ep.r2, 4)) return false;
+    if (!view_vec_ok(out, 8)) return false;  // the epilogue moves 8-channel (16-byte) pieces
+    if (ep.r1.p && !view_vec_ok(ep.r1, 8)) return false;
+    if (ep.r2.p && !view_vec_ok(ep.r2, 8)) return false;
     return true;
 }
 

@@ -347,12 +347,42 @@ __global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, i
     const float2* ys[3] = {y2, y4, y8};
     const View outs[3] = {l2, l4, l8};
     const unsigned rowpix = (unsigned)h * N;
+    // With the pruned masks a thread needs only 4 + 4 + 2 first-pass operands per butterfly for the three bands: all
+    // of them are fetched up front, so the three transforms run back to back without another trip to memory (and no
+    // load is queued behind the stores of the previous band).
+    constexpr int R0 = first_radix(N), NR0 = N / R0, NB0 = NR0 * P, IT0 = (NB0 + THREADS - 1) / THREADS;
+    float2 pre[3][IT0][R0];
+    auto fetch = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int a = ak[k];
+        const int nk = 2 * a - 1;
+        const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
+#pragma unroll
+        for (int q = 0; q < IT0; ++q) {
+            const int i = threadIdx.x + q * THREADS;
+            int p, j;
+            item_to_pj<P, NR0, BLK>(i, p, j);
+#pragma unroll
+            for (int t = 0; t < R0; ++t) {
+                if ((band_zm<PZ>(k) >> t) & 1) continue;
+                const int pos = kept_pos<N>(j + t * NR0, a);
+                const bool ok = pos >= 0 && p0 + p < PT && (NB0 % THREADS == 0 || i < NB0);
+                pre[k][q][t] = ok ? y[y_off(im, p0 + p, h, pos, nk, H)] : make_float2(0.f, 0.f);
+            }
+        }
+    };
+    if constexpr (PZ) {
+        fetch(std::integral_constant<int, 0>{});
+        fetch(std::integral_constant<int, 1>{});
+        fetch(std::integral_constant<int, 2>{});
+    }
     auto band = [&](auto kc) {  // k as a compile-time constant: it selects the pruned first pass
         constexpr int k = decltype(kc)::value;
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
-        auto lf = [&](int c, int p, int, int) {
+        auto lf = [&](int c, int p, int q, int t) {
+            if constexpr (PZ) return pre[k][q][t];
             const int pos = kept_pos<N>(c, a);
             return (pos >= 0 && p0 + p < PT) ? y[y_off(im, p0 + p, h, pos, nk, H)] : make_float2(0.f, 0.f);
         };
