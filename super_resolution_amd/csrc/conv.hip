@@ -391,6 +391,15 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                     y[12 + j] = __uint_as_float(s1[1]);
                 }
                 const int cb = o_blk + m * 32 + hk * 16;
+                if (cout < 32) {  // thin tail (conv_last: 1 or 3 channels): channel-wise epilogue from the low lanes
+                    if (inside && hk == 0 && m == 0) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            if (j < cout)
+                                Elem<bf16_t>::st((bf16_t*)out.p + voff(out, b, pix, j), epilogue_one<bf16_t>(y[j], j, b, pix, ep));
+                    }
+                    continue;
+                }
                 if (!inside || cb >= cout) continue;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) y[j] += ep.bias ? ep.bias[cb + j] : 0.f;
@@ -433,7 +442,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
 
 static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const View& out, const void* wts,
                           long wbs) {
-    if (cout % 32 != 0) return false;
+    const bool thin = cout <= 16;  // HBM-bound anyway: the unused output rows of the 32-wide tile cost nothing that matters
+    if (cout % 32 != 0 && !thin) return false;
     if ((uintptr_t)wts % 16 != 0 || wbs % 8 != 0) return false;
     for (int s = 0; s < in.nseg; ++s) {
         if (in.x[s].C % 32 != 0 || !view_vec_ok(in.x[s], 8) || in.x[s].bs >= (1L << 31)) return false;
@@ -443,6 +453,7 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
                 if (!view_vec_ok(*v, 8) || v->bs >= (1L << 31)) return false;
         }
     }
+    if (thin) return out.p != nullptr;
     if (!view_vec_ok(out, 8)) return false;  // the epilogue moves 8-channel (16-byte) pieces
     if (ep.r1.p && !view_vec_ok(ep.r1, 8)) return false;
     if (ep.r2.p && !view_vec_ok(ep.r2, 8)) return false;

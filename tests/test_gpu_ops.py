@@ -447,7 +447,8 @@ def bf(t):
     return t.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize('cin,cout,h,w', [(32, 32, 16, 32), (64, 32, 19, 45), (64, 64, 33, 70), (96, 32, 40, 48), (192, 64, 17, 31)])
+@pytest.mark.parametrize('cin,cout,h,w', [(32, 32, 16, 32), (64, 32, 19, 45), (64, 64, 33, 70), (96, 32, 40, 48), (192, 64, 17, 31),
+                                          (64, 1, 37, 50), (64, 3, 16, 33)])  # the last two: thin tail (conv_last)
 def test_conv_mfma_bf16_plain(L, cin, cout, h, w):
     """MFMA kernel against an fp64 conv of the same bf16-rounded operands: only fp32 accumulation order and the
     final bf16 rounding differ -> tolerance 2^-8 relative to the output magnitude."""
