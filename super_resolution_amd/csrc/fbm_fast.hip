@@ -264,7 +264,7 @@ __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int 
 
 // ---- columns: forward, mask, inverse x3 ------------------------------------------------------
 template <int N, int P, bool BLK, bool PZ>
-__global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
+__global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
                                                 int a8, const float* __restrict__ rowmask,
                                                 const float2* __restrict__ t1, float2* __restrict__ y2,
                                                 float2* __restrict__ y4, float2* __restrict__ y8,
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void cols(int W, int PT, Inter im, const f
 
 // ---- rows inverse -------------------------------------------------------------------------
 template <typename T, int N, int P, bool BLK, bool PZ>
-__global__ __launch_bounds__(THREADS) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
+__global__ __launch_bounds__(THREADS, 4) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, int a4, int a8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
                                                     const float2* __restrict__ y8) {
