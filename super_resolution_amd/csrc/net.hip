@@ -43,6 +43,9 @@ struct sr_rrdbnet {
             if (layers[i].active) return true;
         return false;
     }
+    // the per-sample weight generation (tiny, latency-bound) runs on a side stream next to the gates kernel
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfEvent> events;
@@ -115,19 +118,20 @@ struct Run {
         return (cb && C % cb == 0) ? blocked_view(ws + off, C, npix, cb) : nhwc_view(ws + off, C, npix);
     }
 
-    void prof_begin(int group) {
+    void prof_begin(int group, hipStream_t on = nullptr) {
         if (!net->prof || rc != SR_OK) return;
+        if (!on) on = st;
         if (net->ev_used == net->events.size()) {
             ProfEvent e{};
             if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
             net->events.push_back(e);
         }
         net->events[net->ev_used].group = group;
-        (void)hipEventRecord(net->events[net->ev_used].a, st);
+        (void)hipEventRecord(net->events[net->ev_used].a, on);
     }
-    void prof_end() {
+    void prof_end(hipStream_t on = nullptr) {
         if (!net->prof || rc != SR_OK || net->ev_used >= net->events.size()) return;
-        (void)hipEventRecord(net->events[net->ev_used].b, st);
+        (void)hipEventRecord(net->events[net->ev_used].b, on ? on : st);
         net->ev_used++;
     }
 
@@ -178,14 +182,19 @@ struct Run {
         ep.bias = lp.bias;
         if (lp.active) {
             float* gates = (float*)(ws + L.gates);
+            // pooled means are ready (low-pass kernels above): fork the weight generation, run the gates meanwhile
+            hipStream_t wgs = net->side ? net->side : st;
+            if (net->side && (hipEventRecord(net->ev_fork, st) != hipSuccess || hipStreamWaitEvent(net->side, net->ev_fork, 0) != hipSuccess)) { rc = SR_ERR_HIP; return; }
+            prof_begin(G_WGEN, wgs);
+            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn, wgs);
+            prof_end(wgs);
+            if (rc != SR_OK) return;
+            if (net->side && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(G_GATES);
             rc = fbm_gates_launch(dtype, B, Hc, Wc, c, lp, gates, st);
             prof_end();
             if (rc != SR_OK) return;
-            prof_begin(G_WGEN);
-            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn, st);
-            prof_end();
-            if (rc != SR_OK) return;
+            if (net->side && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(G_CONV);
             rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, lp.cout, ep, out, st);
             prof_end();
@@ -222,6 +231,9 @@ extern "C" int sr_rrdbnet_create(int num_in_ch, int num_out_ch, int scale, int n
 extern "C" void sr_rrdbnet_destroy(sr_rrdbnet* n) {
     if (!n) return;
     for (auto& kv : n->plans) sr_fbm_plan_destroy(kv.second);
+    if (n->side) (void)hipStreamDestroy(n->side);
+    if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
+    if (n->ev_join) (void)hipEventDestroy(n->ev_join);
     for (auto& e : n->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -268,6 +280,11 @@ extern "C" int sr_rrdbnet_prepare(sr_rrdbnet* n, int Hin, int Win) {
         int rc = sr_fbm_plan_create(key.first, key.second, &pl);
         if (rc != SR_OK) return rc;
         n->plans[key] = pl;
+    }
+    if (!n->side) {  // created here, never in forward (which allocates nothing)
+        SR_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+        SR_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+        SR_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     }
     return SR_OK;
 }
