@@ -141,6 +141,23 @@ int sr_fbm_lowpass(const sr_fbm_plan* plan, int dtype, int B, sr_view x, int ups
 int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in, const sr_layer_params* lp, float* gates,
                  void* stream);
 
+/* The same gates, accumulated segment by segment (bf16 activations only).  The gate conv is linear in its input
+ * channels, so inside a dense block (torch.cat of x, x1..x4 feeding conv1..conv5) every tensor is read ONCE, when it
+ * is produced, for all the layers that will consume it, instead of once per consuming layer:
+ *   logits_j += conv3x3(seg; gate_w_j[:, c0:c0+C])   for each consumer j,
+ * and the consumer for which `seg` is the last input gets gates = 2*sigmoid(logits) written out.
+ * No counterpart call in the reference (FDConv.py:460-461 recomputes the conv over the whole concat per layer). */
+#define SR_MAX_GATE_CONSUMERS 8
+typedef struct {
+    const float* w[3]; /* gate weights of this consumer at the segment's first channel: [C][3*3] per k */
+    const float* b[3]; /* gate biases (used when first != 0) */
+    float* logits;     /* (B,H,W,4) float accumulator of this consumer; read unless first, written unless gates != NULL */
+    float* gates;      /* non-NULL: seg is this consumer's last segment -> write 2*sigmoid(logits) here (B,H,W,4) */
+    int32_t first;     /* non-zero: seg is this consumer's first segment (start from the bias) */
+} sr_gate_consumer;
+int sr_fbm_gates_accumulate(int dtype, int B, int H, int W, sr_view seg, int nconsumers, const sr_gate_consumer* consumers,
+                            void* stream);
+
 /* ---- FDConv weight path --------------------------------------------------------------------
  * basis: the inverse real 2-D DFT (torch.fft.irfft2 at FDConv.py:683) of the alpha-scaled
  * spectrum restricted to each of the 4 frequency groups (FDConv.py:661-680), rearranged to

@@ -42,6 +42,10 @@ class LayerParams(C.Structure):
                 ('loc_w', C.c_void_p), ('ln_w', C.c_void_p), ('ln_b', C.c_void_p)]
 
 
+class GateConsumer(C.Structure):
+    _fields_ = [('w', C.c_void_p * 3), ('b', C.c_void_p * 3), ('logits', C.c_void_p), ('gates', C.c_void_p), ('first', C.c_int32)]
+
+
 _SIGS = {
     'sr_strerror': (C.c_char_p, [C.c_int]),
     'sr_last_hip_error': (C.c_int, []),
@@ -57,6 +61,7 @@ _SIGS = {
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_fbm_gates': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.POINTER(LayerParams), C.c_void_p,
                                C.c_void_p]),
+    'sr_fbm_gates_accumulate': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, C.c_int, C.POINTER(GateConsumer), C.c_void_p]),
     'sr_fdconv_basis_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'sr_fdconv_basis': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),

@@ -138,6 +138,20 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
                      int pooled_ld, void* ws, hipStream_t st);
 int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_layer_params& lp, float* gates,
                      hipStream_t st);
+// consumers of sr_fbm_gates_accumulate (device-side mirror of sr_gate_consumer)
+struct GateCons {
+    const float* w[3];
+    const float* b[3];
+    float* logits;
+    float* gates;
+    int first;
+};
+struct GateConsList {
+    int n;
+    GateCons c[SR_MAX_GATE_CONSUMERS];
+};
+
+int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, hipStream_t st);  // bf16; SR_NOT_ELIGIBLE
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,
                      hipStream_t st);
 

@@ -196,6 +196,140 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Segment-wise accumulation (sr_fbm_gates_accumulate): one segment (<= 64 channels), up to 8 consumer layers.
+// The wave's activation fragments stay in registers while it loops over the consumers (A operand = that consumer's
+// 27 x C weight slice); per consumer the T image goes through the same LDS buffer and the 9-tap sum is added to the
+// consumer's logits (or finished as 2*sigmoid into the gates buffer).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H, int W, GateConsList cl) {
+    extern __shared__ __attribute__((aligned(16))) char glds[];
+    float* T = (float*)glds;                                  // [GNT*32][27]
+    char* A = glds + GNT * 32 * GTROW * sizeof(float);        // [consumer][32][C*2 + 16] bf16 rows, padded
+    const int C = seg.C;
+    const int astride = C * 2 + 16;
+    const int tilesx = (W + GMW - 1) / GMW;
+    const unsigned tiles = (unsigned)tilesx * ((H + GMH - 1) / GMH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hk = lane >> 5;
+    for (int ci = 0; ci < cl.n; ++ci) {
+        const float* w0 = cl.c[ci].w[0];
+        const float* w1 = cl.c[ci].w[1];
+        const float* w2 = cl.c[ci].w[2];
+        for (int it = tid; it < 32 * C; it += 256) {
+            const int c = it % C, row = it / C;
+            float v = 0.f;
+            if (row < 27) {
+                const float* wk = row % 3 == 0 ? w0 : (row % 3 == 1 ? w1 : w2);
+                v = wk[(long)c * 9 + row / 3];
+            }
+            *(bf16_t*)(A + (ci * 32 + row) * astride + c * 2) = f32_to_bf16(v);
+        }
+    }
+    const unsigned total = tiles * (unsigned)B;
+    const unsigned xj = blockIdx.x & 7u, q8 = total >> 3, r8 = total & 7u;
+    const unsigned wstart = xj * q8 + (xj < r8 ? xj : r8), wend = wstart + q8 + (xj < r8 ? 1u : 0u);
+    const unsigned wstride = (gridDim.x - xj + 7u) >> 3;
+    const int nks = C / 16;  // 1..4
+    for (unsigned lin = wstart + (blockIdx.x >> 3); lin < wend; lin += wstride) {
+        const int tile = lin % tiles, b = lin / tiles;
+        const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
+        // this wave's N-tiles: wave, wave + 4, wave + 8 (< GNT = 11); all their fragments are fetched once
+        g_short8 frag[3][4];
+        bool ok[3];
+        int slot[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int nt = wave + 4 * u;
+            slot[u] = nt * 32 + r;
+            const int py = slot[u] / GPW, px = slot[u] - py * GPW;
+            const int h = h0 + py - 1, w = w0p + px - 1;
+            ok[u] = nt < GNT && slot[u] < GSLOTS && h >= 0 && h < H && w >= 0 && w < W;
+            const long ps = (long)min(max(h, 0), H - 1) * W + min(max(w, 0), W - 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                frag[u][t] = *(const g_short8*)((const bf16_t*)seg.p + voff(seg, b, ps, min(16 * t, C - 16) + hk * 8));
+        }
+        const int ty = tid / GMW, tx = tid % GMW;
+        const int h = h0 + ty, w = w0p + tx;
+        for (int ci = 0; ci < cl.n; ++ci) {
+            __syncthreads();  // weights staged / T of the previous consumer (or tile) consumed
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (wave + 4 * u >= GNT) continue;
+                g_float16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= nks) break;
+                    const g_short8 afrag = *(const g_short8*)(A + (ci * 32 + r) * astride + (16 * t + hk * 8) * 2);
+                    const g_short8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, ok[u] ? frag[u][t] : z, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * hk;
+                    if (row < 27) T[slot[u] * GTROW + row] = acc[i];
+                }
+            }
+            __syncthreads();
+            if (h < H && w < W) {
+                const GateCons& gc = cl.c[ci];
+                const long pix = ((long)b * H + h) * W + w;
+                float lg[3];
+                if (gc.first) {
+                    lg[0] = gc.b[0][0];
+                    lg[1] = gc.b[1][0];
+                    lg[2] = gc.b[2][0];
+                } else {
+                    const float4 p = ((const float4*)gc.logits)[pix];
+                    lg[0] = p.x;
+                    lg[1] = p.y;
+                    lg[2] = p.z;
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float* t = T + ((ty + tap / 3) * GPW + tx + tap % 3) * GTROW + tap * 3;
+                    lg[0] += t[0];
+                    lg[1] += t[1];
+                    lg[2] += t[2];
+                }
+                float4 g;
+                if (gc.gates) {
+                    g.x = 2.0f / (1.0f + expf(-lg[0]));
+                    g.y = 2.0f / (1.0f + expf(-lg[1]));
+                    g.z = 2.0f / (1.0f + expf(-lg[2]));
+                    g.w = 0.f;
+                    ((float4*)gc.gates)[pix] = g;
+                } else {
+                    g = make_float4(lg[0], lg[1], lg[2], 0.f);
+                    ((float4*)gc.logits)[pix] = g;
+                }
+            }
+        }
+    }
+}
+
+int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, hipStream_t st) {
+    if (cl.n < 1 || cl.n > SR_MAX_GATE_CONSUMERS) return SR_ERR_ARG;
+    if (seg.C % 16 || seg.C > 64 || !view_vec_ok(seg, 8)) return SR_NOT_ELIGIBLE;
+    const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + (size_t)cl.n * 32 * (seg.C * 2 + 16);
+    SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_acc_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
+    if (nblk >= (1L << 31)) return SR_ERR_ARG;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        SR_HIP(hipGetDevice(&dev));
+        SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const long per_cu = std::max<long>(1, std::min<long>(4, (160 * 1024) / (long)lds));
+    fbm_gates_acc_mfma<<<dim3((unsigned)std::min<long>(nblk, per_cu * ncu)), 256, lds, st>>>(seg, B, H, W, cl);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
 static bool gates_mfma_eligible(const Concat& in) {
     if (in.ctot > 1024) return false;
     for (int s = 0; s < in.nseg; ++s) {
@@ -252,6 +386,28 @@ extern "C" int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in,
     SR_REQUIRE(c.ctot == lp->cin);
     for (int k = 0; k < 3; ++k) SR_REQUIRE(lp->gate_w[k] && lp->gate_b[k]);
     return fbm_gates_launch(dtype, B, H, W, c, *lp, gates, (hipStream_t)stream);
+}
+
+extern "C" int sr_fbm_gates_accumulate(int dtype, int B, int H, int W, sr_view seg, int nconsumers,
+                                       const sr_gate_consumer* consumers, void* stream) {
+    SR_REQUIRE(dtype == SR_BF16 && B > 0 && H > 0 && W > 0 && seg.p && consumers);
+    SR_REQUIRE(nconsumers >= 1 && nconsumers <= SR_MAX_GATE_CONSUMERS && view_block_ok(seg) && seg.C > 0 && seg.c0 >= 0);
+    GateConsList cl{};
+    cl.n = nconsumers;
+    for (int i = 0; i < nconsumers; ++i) {
+        const sr_gate_consumer& c = consumers[i];
+        for (int k = 0; k < 3; ++k) {
+            SR_REQUIRE(c.w[k] && (c.b[k] || !c.first));
+            cl.c[i].w[k] = c.w[k];
+            cl.c[i].b[k] = c.b[k];
+        }
+        SR_REQUIRE(c.logits || (c.first && c.gates));
+        cl.c[i].logits = c.logits;
+        cl.c[i].gates = c.gates;
+        cl.c[i].first = c.first ? 1 : 0;
+    }
+    const int rc = fbm_gates_acc_launch(B, H, W, to_view(seg, (long)H * W), cl, (hipStream_t)stream);
+    return rc == SR_NOT_ELIGIBLE ? SR_ERR_ARG : rc;
 }
 
 extern "C" void sr_debug_force_generic_gates(int on) { sr::g_force_generic_gates = on; }

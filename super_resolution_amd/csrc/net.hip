@@ -57,7 +57,7 @@ namespace {
 enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4 };
 
 struct Layout {
-    size_t in0, f0, trunk[3], xg[4], band64, bandg[4], gates, pooled, wdyn, fft, u1, band_u1, u2, u3, band_hr, outp;
+    size_t in0, f0, trunk[3], xg[4], band64, bandg[4], gates, logit[5], pooled, wdyn, fft, u1, band_u1, u2, u3, band_hr, outp;
     size_t total;
 };
 
@@ -94,6 +94,7 @@ Layout make_layout(const sr_rrdbnet* net, int dtype, int B, int H, int W) {
         L.band_u1 = carve(3 * n2 * net->nf * es);
         L.band_hr = carve(3 * n4 * net->nf * es);
         L.gates = carve(n4 * 4 * sizeof(float));
+        for (int i = 0; i < 5; ++i) L.logit[i] = carve(n1 * 4 * sizeof(float));  // dense-block gate accumulators
         const int cmax = net->nf + 4 * net->gc;
         L.pooled = carve((size_t)B * cmax * sizeof(float));
         L.wdyn = carve((size_t)B * 9 * net->nf * cmax * es);
@@ -156,7 +157,9 @@ struct Run {
     }
 
     // one conv layer: segs = virtual concat; conv runs at resolution `res`
-    void conv(int li, Tensor** segs, int nseg, int res, const Epilogue& ep_in, View out) {
+    // rdb_k >= 0: layer li is conv(rdb_k + 1) of a dense block whose conv1 is layer li - rdb_k; its gates are then
+    // accumulated segment by segment (the newest segment is read once, for this and all later convs of the block)
+    void conv(int li, Tensor** segs, int nseg, int res, const Epilogue& ep_in, View out, int rdb_k = -1) {
         if (rc != SR_OK) return;
         const sr_layer_params& lp = net->layers[li];
         const int Hc = H << res, Wc = W << res;
@@ -191,7 +194,30 @@ struct Run {
             if (rc != SR_OK) return;
             if (net->side && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(G_GATES);
-            rc = fbm_gates_launch(dtype, B, Hc, Wc, c, lp, gates, st);
+            bool done = false;
+            if (rdb_k >= 0 && dtype == SR_BF16 && nseg == rdb_k + 1) {
+                GateConsList cl{};
+                const int cstart = c.cstart[rdb_k];  // first concat channel of the newest segment
+                bool okc = true;
+                for (int j = rdb_k; j < 5; ++j) {
+                    const sr_layer_params& lj = net->layers[li - rdb_k + j];
+                    okc = okc && lj.active;
+                    GateCons& g = cl.c[cl.n++];
+                    for (int k = 0; k < 3; ++k) {
+                        g.w[k] = lj.gate_w[k] + (size_t)cstart * 9;
+                        g.b[k] = lj.gate_b[k];
+                    }
+                    g.logits = (float*)(ws + L.logit[j]);
+                    g.gates = j == rdb_k ? gates : nullptr;
+                    g.first = rdb_k == 0;
+                }
+                if (okc) {
+                    const int r2 = fbm_gates_acc_launch(B, Hc, Wc, segs[rdb_k]->x, cl, st);
+                    if (r2 == SR_OK) done = true;
+                    else if (r2 != SR_NOT_ELIGIBLE) rc = r2;
+                }
+            }
+            if (!done && rc == SR_OK) rc = fbm_gates_launch(dtype, B, Hc, Wc, c, lp, gates, st);
             prof_end();
             if (rc != SR_OK) return;
             if (net->side && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
@@ -370,7 +396,7 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
             for (int k = 0; k < 4; ++k) {
                 Epilogue ep{};
                 ep.lrelu = 1;
-                R.conv(li++, segs, k + 1, 0, ep, xg[k].x);
+                R.conv(li++, segs, k + 1, 0, ep, xg[k].x, k);
             }
             Tensor* outp = nullptr;
             for (int i = 0; i < 3; ++i)
@@ -382,7 +408,7 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
                 ep.r2 = blk_in->x;
                 ep.s2 = 0.2f;
             }
-            R.conv(li++, segs, 5, 0, ep, outp->x);
+            R.conv(li++, segs, 5, 0, ep, outp->x, 4);
             cur = outp;
         }
     }

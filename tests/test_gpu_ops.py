@@ -391,6 +391,46 @@ def run_conv(L, dt, xs, w, bias=None, lrelu=0, r1=None, s1=0.0, r2=None, s2=0.0,
     return nchw(out)
 
 
+@pytest.mark.parametrize('cb', [0, 32])
+def test_fbm_gates_accumulate_dense_block(L, cb):
+    """Segment-wise gate accumulation over a dense block (x: 64 ch, x1..x4: 32 ch, five consumer layers) against the
+    per-layer gates kernel on the same bf16 data and against the oracle."""
+    lib = L.lib()
+    B, H, W = 2, 20, 37
+    segc = [64, 32, 32, 32, 32]
+    xs = [bf(rnd((B, c, H, W), 300 + i)) for i, c in enumerate(segc)]
+    if cb:
+        xd = [blocked(x, torch.bfloat16, cb) for x in xs]
+        mk = L.blocked_view
+    else:
+        xd = [nhwc(x, torch.bfloat16) for x in xs]
+        mk = L.view
+    cins = [64, 96, 128, 160, 192]
+    gw = [[dev(rnd((cin, 9), 400 + 10 * j + k, 0.05)).contiguous() for k in range(3)] for j, cin in enumerate(cins)]
+    gb = [[dev(rnd((1,), 500 + 10 * j + k)).contiguous() for k in range(3)] for j in range(5)]
+    logits = [torch.full((B, H, W, 4), float('nan'), device='cuda:0') for _ in range(5)]
+    gates = [torch.full((B, H, W, 4), float('nan'), device='cuda:0') for _ in range(5)]
+    c0 = 0
+    for s_ in range(5):  # segment s_ feeds consumers s_ .. 4; it is the last input of consumer s_
+        cons = (L.GateConsumer * (5 - s_))()
+        for n_, j in enumerate(range(s_, 5)):
+            for k in range(3):
+                cons[n_].w[k] = gw[j][k].data_ptr() + c0 * 9 * 4
+                cons[n_].b[k] = gb[j][k].data_ptr()
+            cons[n_].logits = logits[j].data_ptr()
+            cons[n_].gates = gates[j].data_ptr() if j == s_ else None
+            cons[n_].first = 1 if s_ == 0 else 0
+        L.check(lib.sr_fbm_gates_accumulate(1, B, H, W, mk(xd[s_]), 5 - s_, cons, st(L)))
+        c0 += segc[s_]
+    torch.cuda.synchronize()
+    for j in range(5):
+        xcat = torch.cat(xs[:j + 1], dim=1).double()
+        wts = [gw[j][k].cpu().to(torch.bfloat16).double().view(1, cins[j], 3, 3) for k in range(3)]
+        gref = fr.fbm_gates(xcat, wts, [gb[j][k].cpu().double() for k in range(3)]).float()
+        got = gates[j].cpu()[..., :3].permute(0, 3, 1, 2)
+        assert (got - gref).abs().max().item() < 3e-5, j
+
+
 def ref_conv(xs, w, bias=None, lrelu=0, r1=None, s1=0.0, r2=None, s2=0.0, bands=None, gates=None, ups=0,
              per_sample=False):
     x = torch.cat(xs, 1).double()
