@@ -19,6 +19,9 @@
 
 #include <vector>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 #include "fbm_plan.h"
@@ -252,7 +255,12 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
 }
 
 int g_force_generic_fft = 0;  // test hook
-int g_force_fft_lowpass = 1;  // the MFMA (DFT-as-GEMM) path of fbm_mfma.hip is opt-in: correct, not yet faster than the FFT
+// The MFMA (DFT-as-GEMM) path of fbm_mfma.hip is opt-in (SR_AMD_LOWPASS=mfma, or the debug hook below).
+static int lowpass_default() {
+    const char* e = getenv("SR_AMD_LOWPASS");
+    return (e && !strcmp(e, "mfma")) ? 0 : 1;
+}
+int g_force_fft_lowpass = lowpass_default();
 
 static Radix make_radix(const int* r, int nf) {
     Radix x{};

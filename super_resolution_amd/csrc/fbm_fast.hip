@@ -217,6 +217,20 @@ __device__ __forceinline__ unsigned y_off(const Inter& it, int gp, int h, int po
     return ((((unsigned)(gp >> it.QL) * H + h) * nk + pos) << it.QL) + (gp & (it.Q - 1));
 }
 
+// Workgroup -> (x, y) of the launch grid.  With groups of fewer than 16 pairs an intermediate row is narrower than a
+// 128-byte line, and the workgroups that complete a line are neighbours along x: the hardware deals consecutive
+// workgroups to different XCDs (different L2s, each left with a partial line), so those launches walk the grid
+// XCD-contiguously instead.
+__device__ __forceinline__ void block_xy(const Inter& it, unsigned& bx, unsigned& by) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    if (it.Q < 16) {
+        const unsigned t = xcd_remap(by * gridDim.x + bx, gridDim.x * gridDim.y);
+        bx = t % gridDim.x;
+        by = t / gridDim.x;
+    }
+}
+
 // Bit t of the result: first-pass operand range [t * N/R, (t + 1) * N/R) holds no kept index of [0, a) u (N - a, N).
 template <int N>
 __host__ __device__ inline int zero_mask(int a) {
@@ -246,8 +260,10 @@ __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int 
                                                     const float2* __restrict__ tw, int a2, float2* __restrict__ t1) {
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int p0 = blockIdx.y * P;
+    unsigned bx, by;
+    block_xy(im, bx, by);
+    const int b = bx / H, h = bx % H;
+    const int p0 = by * P;
     const int n2 = 2 * a2 - 1;
     const unsigned rowpix = (unsigned)(h >> ups) * (N >> ups);
     const T* xb = (const T*)x.p + (long)b * x.bs;
@@ -273,8 +289,10 @@ __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, cons
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
     const int n2 = 2 * a2 - 1;
-    const int b = blockIdx.x / n2, idx = blockIdx.x % n2;
-    const int p0 = blockIdx.y * P;
+    unsigned bx, by;
+    block_xy(im, bx, by);
+    const int b = bx / n2, idx = bx % n2;
+    const int p0 = by * P;
     const int col = idx < a2 ? idx : idx + (W - n2);  // full-spectrum column of this block
     const float2* t1b = t1 + ((long)b * im.NPG * n2 * H << im.QL);
     auto lf = [&](int h, int p, int, int) {
@@ -340,8 +358,10 @@ __global__ __launch_bounds__(THREADS, 4) void rows_inv(View l2, View l4, View l8
                                                     const float2* __restrict__ y8) {
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int p0 = blockIdx.y * P;
+    unsigned bx, by;
+    block_xy(im, bx, by);
+    const int b = bx / H, h = bx % H;
+    const int p0 = by * P;
     const float norm = 1.0f / ((float)H * (float)N);
     const int ak[3] = {a2, a4, a8};
     const float2* ys[3] = {y2, y4, y8};

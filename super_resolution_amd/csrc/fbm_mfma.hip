@@ -184,7 +184,7 @@ __device__ __forceinline__ T sel3(int i, T a, T b, T c) {
 constexpr int RTHREADS = 256;
 
 template <int MODE>
-__global__ __launch_bounds__(RTHREADS) void mf_rows(RowsArgs a) {
+__global__ __launch_bounds__(RTHREADS, 2) void mf_rows(RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
