@@ -255,10 +255,11 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
 }
 
 int g_force_generic_fft = 0;  // test hook
-// The MFMA (DFT-as-GEMM) path of fbm_mfma.hip is opt-in (SR_AMD_LOWPASS=mfma, or the debug hook below).
-static int lowpass_default() {
+// bf16 planes of shapes that fbm_mfma.hip covers take its DFT-as-GEMM kernels; SR_AMD_LOWPASS=fft (or the debug hook
+// below) keeps them on the FFT kernels.
+int lowpass_default() {
     const char* e = getenv("SR_AMD_LOWPASS");
-    return (e && !strcmp(e, "mfma")) ? 0 : 1;
+    return (e && !strcmp(e, "fft")) ? 1 : 0;
 }
 int g_force_fft_lowpass = lowpass_default();
 
@@ -321,7 +322,7 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 using namespace sr;
 
 extern "C" void sr_debug_force_generic_fft(int on) { sr::g_force_generic_fft = on; }
-extern "C" void sr_debug_force_fft_lowpass(int on) { sr::g_force_fft_lowpass = on; }
+extern "C" void sr_debug_force_fft_lowpass(int on) { sr::g_force_fft_lowpass = on < 0 ? sr::lowpass_default() : on; }
 
 extern "C" int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host) {
     SR_REQUIRE(H > 0 && W > 0 && rows_host && cols_host);

@@ -1,30 +1,41 @@
 // FBM low-pass planes on the matrix cores (bf16 activations, H and W multiples of 32 up to 512).
 //
-// The three box masks keep few frequencies, so the masked FFT round trip is three small dense products per plane,
-//     T = x Qw         rows forward  : x-basis coefficients of every image row            (K = W,        M = jw)
-//     U_k = B2_k (Ph^T T)   columns  : y-coefficients, mask weights, back to rows         (K = H / nh_k, M = nh / H)
-//     L_k = U_k Qw_k^T   rows inverse : synthesis from the first nw[k] coefficients        (K = nw[k],    M = W)
+// The three box masks keep few frequencies, so the masked FFT round trip is four small dense products per plane,
+//     T   = x Qw            analysis along W   (K = W,      M = jw)      bf16 image rows -> x-basis coefficients
+//     S   = Ph^T T          analysis along H   (K = H,      M = nh)      -> coefficients of both axes
+//     U_k = P_k S'_k        synthesis along H  (K = nhk[k], M = H)       mask weights of band k, back to rows
+//     L_k = U_k Qw_k^T      synthesis along W  (K = nw[k],  M = W)       -> the three bf16 planes
 // in REAL orthonormal Fourier bases (q_0 = 1/sqrt(W); q_2c = sqrt(2/W) cos, q_2c+1 = sqrt(2/W) sin; index 1 is an
 // all-zero dummy so that (cos, sin) pairs stay 2-aligned).  The VALU FFT of fbm_fast.hip is bound by vector
-// instruction issue (~60 % VALU busy); the same work as v_mfma_f32_32x32x16_f16 GEMMs leaves the kernels bound by
-// the HBM stream of x, the fp16 intermediates and the three output planes.
+// instruction issue and by its fp32 complex intermediates; as v_mfma_f32_32x32x16_f16 GEMMs the arithmetic is a few
+// per cent of the time and the kernels stream x, the fp16 intermediates and the three output planes.
+//
+// Kernel shape (both kernels): one persistent workgroup of 8 waves per CU.  Every wave keeps ITS slice of the basis
+// (32 or 64 basis functions x all k) in 128 registers for the whole kernel, so the only global loads are the data
+// rows of the NEXT group, issued before the matrix phase of the current one and parked in registers until the
+// current image has been consumed (two LDS images, one barrier per group).  A wave's loads are therefore always
+// ahead of its own stores in the in-order memory pipe -- the reason the first version of this path (basis streamed
+// from L2 behind the output stores) could not overlap anything.
 //
 // Row masks of the reference are not symmetric in +-fy (nearest resize of the 64-row prototype).  With
 // s_f = (m[+f] + m[-f]) / 2 and d_f = (m[+f] - m[-f]) / 2 the filtered coefficient columns A (cos c) and B (sin c)
 // of a column frequency c > 0 are
 //     A' = sum_n s_n SA_n p_n + sum_f d_f (SB_cos,f p_sin,f - SB_sin,f p_cos,f)
 //     B' = sum_n s_n SB_n p_n + sum_f d_f (SA_sin,f p_cos,f - SA_cos,f p_sin,f)
-// (SA, SB = y-coefficients of A, B).  d_f is non-zero for a handful of boundary rows only: they become one extra
-// 16-deep k-step whose data rows hold the partner column's coefficients (sign folded in) -- everything stays one GEMM.
+// (SA, SB = y-coefficients of A, B).  The synthesis basis is shared by the three bands (it lives in registers), so
+// the weights go on the data: y-coefficients below the first row with s < 1 enter with weight one straight from the
+// staged image ("main" k-steps); the at most 32 rows after it (weights 1, 1/2, 0 and the partner terms) are rebuilt
+// per band into a small "window" image, s S_own +- d S_partner, and multiplied with the same basis registers.
 //
-// Every product has the data operand [k][32 channels] (channels innermost in memory, as the tensors are) and the
-// basis operand [m][k] (k innermost, read straight from L2).  Data tiles are staged row-major in LDS (plain 16-byte
-// stores of what was loaded) and read through ds_read_b64_tr_b16, which hands each lane the 4 k-values of its
-// channel: no software transpose.  D = data^T x basis^T puts 4 consecutive channels of one output row in a lane;
-// v_permlane32_swap pairs lanes l / l+32 so that each lane stores 32 contiguous bytes.
+// Every product has the data operand [k][32 channels] (channels innermost in memory, as the tensors are).  Data tiles
+// are staged row-major in LDS (plain 16-byte stores of what was loaded) and read through ds_read_b64_tr_b16, which
+// hands each lane the 4 k-values of its channel: no software transpose.  D = data^T x basis^T puts 4 consecutive
+// channels of one output row in a lane; v_permlane32_swap pairs lanes l / l+32 so that each lane stores 32
+// contiguous bytes.
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -39,26 +50,34 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s4;
 
 constexpr int THREADS = 512;
-constexpr int G = 4;              // batch items (image rows / coefficient columns) per workgroup pass: 128 GEMM rows
-constexpr int ROWB = G * 32 * 2;  // LDS image row: G items x 32 channels x fp16 = 256 B
-// Basis tables are stored fragment-major: the 64 x 8 halfs one wave loads for (row tile nt, k-step ks) are 1 KiB
-// contiguous (lane = 32 * (k / 8 % 2) + row % 32), so a fragment load is eight fully used cache lines instead of 32
-// quarter-used ones -- the tables are re-read from L2 by every workgroup for every batch group.
+constexpr int IMG_B = 64 * 1024;  // one staged data image: K rows x G items x 32 channels x fp16
+// Basis tables are stored fragment-major: the 64 x 8 halfs one wave needs for (row tile nt, k-step ks) are 1 KiB
+// contiguous (lane = 32 * (k / 8 % 2) + row % 32).
 constexpr int FRAG = 64 * 8;
 __host__ __device__ inline size_t frag_index(int row, int k, int nks) {
     return ((size_t)((row >> 5) * nks + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
 }
 
-// Byte offset of 16-byte chunk ch (0..15) of image row `row`: XOR swizzle that keeps both the 16-byte row stores and
-// the transposed reads conflict-free (programming guide T10, image (b)).
-__device__ __forceinline__ int img_off(int row, int ch) { return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+// Byte offset of 16-byte chunk ch of image row `row` (a row = G items x 64 bytes): XOR swizzles that keep both the
+// 16-byte row stores and the transposed reads spread over the banks (programming guide T10, image (b)).
+template <int G>
+__device__ __forceinline__ int img_off(int row, int ch);
+template <>
+__device__ __forceinline__ int img_off<4>(int row, int ch) {
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+template <>
+__device__ __forceinline__ int img_off<2>(int row, int ch) {
+    return 128 * row + 16 * (ch ^ ((row & 3) << 1));
+}
 
-// Address of this lane's share of the transposed read that delivers, for M-tile mt (= batch item), the k-values
+// Address of this lane's share of the transposed read that delivers, for item mt, the k-values
 // 8 * (lane >> 5) + 4 * half + {0..3} of k-step 0: lane 4q + p of a 16-lane group supplies row q, columns 4p..4p+3.
+template <int G>
 __device__ __forceinline__ int tr_addr(int lane, int mt, int half) {
     const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int row = 8 * (g4 >> 1) + 4 * half + q;
-    return img_off(row, mt * 4 + 2 * (g4 & 1) + (p >> 1)) + 8 * (p & 1);
+    return img_off<G>(row, mt * 4 + 2 * (g4 & 1) + (p >> 1)) + 8 * (p & 1);
 }
 
 __device__ __forceinline__ half8 tr_read(const char* img, int addr_lo, int addr_hi) {
@@ -73,41 +92,6 @@ __device__ __forceinline__ half8 tr_read(const char* img, int addr_lo, int addr_
     u.p.a = lo;
     u.p.b = hi;
     return u.v;
-}
-
-// acc[mt][j] += data(mt)^T x basis(tile j)^T over `nks` k-steps of 16 starting at image row `row0`.
-// bptr[j]: this lane's 8 basis values of the first k-step (tables are fragment-major, see frag_index).  The basis streams from L2 and is
-// the only operand with a long latency: PF k-steps of fragments stay in flight per wave, in a rotating register
-// queue.  Every load is unconditional (indices clamped to the last k-step): a branch around a load makes the
-// compiler drain the whole memory pipeline at the join.  Tiles beyond the matrix (clamped pointers) are computed
-// and dropped by the caller: a uniform branch around each MFMA would split the loop body into tiny blocks.
-template <int NTW, int PF>
-__device__ __forceinline__ void mma_steps(f32x16 (&acc)[G][NTW], const char* img, int row0, int nks, const h16* const (&bptr)[NTW],
-                                          const int (&ta)[G][2]) {
-    half8 ring[PF][NTW];
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) ring[u][j] = *(const half8*)(bptr[j] + min(u, nks - 1) * FRAG);
-#pragma unroll 1
-    for (int ks = 0; ks < nks; ++ks) {
-        half8 bc[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            bc[j] = ring[0][j];
-#pragma unroll
-            for (int u = 0; u + 1 < PF; ++u) ring[u][j] = ring[u + 1][j];
-            ring[PF - 1][j] = *(const half8*)(bptr[j] + min(ks + PF, nks - 1) * FRAG);
-        }
-        const char* base = img + (row0 + ks * 16) * ROWB;
-#pragma unroll
-        for (int mt = 0; mt < G; ++mt) {
-            const half8 a = tr_read(base, ta[mt][0], ta[mt][1]);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-                acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bc[j], acc[mt][j], 0, 0, 0);
-        }
-    }
 }
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
@@ -155,298 +139,356 @@ __device__ __forceinline__ uint4 bf16x8_to_h16x8(uint4 v) {
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// rows forward (MODE 0) and rows inverse (MODE 2): one basis, K in chunks of 256 through two LDS images
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int KC = 256;
-constexpr int IMG_B = KC * ROWB;  // 64 KiB
-
-struct RowsArgs {
-    View x;  // MODE 0 input (bf16)
-    int ups;
-    View out[3];     // MODE 2 outputs (bf16)
-    h16* T;          // MODE 0 output / [B*CG][H][jw][32]
-    const h16* U[3]; // MODE 2 input  / [B*CG][H][nw[k]][32]
-    const h16* basis;
-    int nks;  // k-steps per row tile of the (fragment-major) basis table
-    int B, CG, H, W, jw, nw[3];
-};
-
 template <typename T>
 __device__ __forceinline__ T sel3(int i, T a, T b, T c) {
     return i == 0 ? a : (i == 1 ? b : c);
 }
 
-// Workgroups of 4 waves with one 64 KiB image each: two of them share a CU, so that one streams its output rows (a
-// wave's later loads cannot complete before its earlier stores have drained -- one in-order counter) while the other
-// multiplies.  Per batch group: stage the K x 128 data chunk, barrier, then every wave runs its basis-row tiles
-// {wave, wave + 4, ...} two at a time (128 accumulator registers) and stores them.
-constexpr int RTHREADS = 256;
+__device__ __forceinline__ half8 zero_h8() {
+    half8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (h16)0.f;
+    return z;
+}
 
-template <int MODE>
-__global__ __launch_bounds__(RTHREADS, 2) void mf_rows(RowsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int M = MODE == 0 ? a.jw : a.W;
-    const int NT = (M + 31) / 32;
-    int ta[G][2];
+// Thread index rebuilt from the lane counter and the (scalar) wave index.  Volatile: the per-thread addresses derived
+// from it are then recomputed where they are used instead of being hoisted out of the group loop and spilled (a scratch
+// reload queues behind the output stores like any other memory operation).
+__device__ __forceinline__ int fresh_tid(int wave) {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return wave * 64 + l;
+}
+
+__device__ __forceinline__ void zero_acc(f32x16& a) {
 #pragma unroll
-    for (int mt = 0; mt < G; ++mt) {
-        ta[mt][0] = tr_addr(lane, mt, 0);
-        ta[mt][1] = tr_addr(lane, mt, 1);
-    }
-    const int Ws = a.W >> a.ups;
-    const int ngroups = a.B * a.CG * (a.H / G);
-    const int oct = tid & 3, kk0 = tid >> 2;  // item i -> batch member i >> 2, row kk0 + 64 (i & 3), channel octet oct
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int bcg = grp / (a.H / G), h0 = (grp % (a.H / G)) * G;
-        const int b = bcg / a.CG, cg = bcg % a.CG;
-#pragma unroll 1
-        for (int band = 0; band < (MODE == 0 ? 1 : 3); ++band) {
-            const int K = MODE == 0 ? a.W : a.nw[band];
-            const int nch = (K + KC - 1) / KC;
-            const int npass = nch == 1 ? (NT + 7) / 8 : 1;  // several chunks: the accumulators persist, NT <= 8 (host check)
-            const h16* usrc = MODE == 2 ? a.U[band] : nullptr;
-            f32x16 acc[G][2];
-#pragma unroll 1
-            for (int chunk = 0; chunk < nch; ++chunk) {
-                const int kc = min(K - chunk * KC, KC), kc16 = (kc + 15) & ~15;
-                uint4 pre[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int g = i >> 2, kk = kk0 + 64 * (i & 3), k = min(chunk * KC + kk, K - 1);  // clamped, zeroed below
-                    if (MODE == 0) {
-                        const unsigned pix = (unsigned)((h0 + g) >> a.ups) * Ws + (k >> a.ups);
-                        pre[i] = *(const uint4*)((const bf16_t*)a.x.p + (long)b * a.x.bs + voff32(a.x, pix, cg * 32 + oct * 8));
-                    } else {
-                        pre[i] = *(const uint4*)(usrc + (((long)bcg * a.H + h0 + g) * K + k) * 32 + oct * 8);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int g = i >> 2, kk = kk0 + 64 * (i & 3);
-                    uint4 v = MODE == 0 ? bf16x8_to_h16x8(pre[i]) : pre[i];
-                    if (kk >= kc) v = make_uint4(0u, 0u, 0u, 0u);
-                    if (kk < kc16) *(uint4*)(lds + img_off(kk, g * 4 + oct)) = v;
-                }
-                __syncthreads();
-#pragma unroll 1
-                for (int pass = 0; pass < npass; ++pass) {
-                    if (chunk == 0) {
-#pragma unroll
-                        for (int mt = 0; mt < G; ++mt)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                                for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
-                    }
-                    const int nt[2] = {wave + 8 * pass, wave + 8 * pass + 4};
-                    const h16* bptr[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) bptr[j] = a.basis + ((size_t)(min(nt[j], NT - 1) * a.nks + chunk * (KC / 16)) * 64 + lane) * 8;
-                    mma_steps<2, 4>(acc, lds, 0, kc16 >> 4, bptr, ta);
-                    if (chunk + 1 < nch) continue;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int m = nt[j] * 32 + (lane & 31);
-#pragma unroll
-                        for (int mt = 0; mt < G; ++mt) {
-                            uint4 lo, hi;
-                            tile_to_rows<MODE == 2>(acc[mt][j], 1.0f, lo, hi);
-                            if (m >= M) continue;
-                            uint4* dst;
-                            if (MODE == 0) {
-                                dst = (uint4*)(a.T + (((long)bcg * a.H + h0 + mt) * a.jw + m) * 32 + (lane >> 5) * 16);
-                            } else {
-                                const View o = a.out[band];
-                                dst = (uint4*)((bf16_t*)o.p + (long)b * o.bs + voff32(o, (unsigned)(h0 + mt) * a.W + m, cg * 32 + (lane >> 5) * 16));
-                            }
-                            dst[0] = lo;
-                            dst[1] = hi;
-                        }
-                    }
-                }
-                __syncthreads();  // image consumed
-            }
-        }
-    }
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// columns: y-analysis (K = H in chunks of 128), mask weights + asymmetric partner rows, y-synthesis per band
+// analysis: out[item][m] = sum_k data[item][k] basis[m][k];  K <= 512, M <= 256: one 32-function basis tile per wave,
+// two items per staged image (K rows x 128 bytes)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int KC1 = 128;
-constexpr int IMG1_B = KC1 * ROWB;         // 32 KiB, two of them
-constexpr int IMG2_ROWS = 256 + 3 * 16;    // coefficients + 16 partner rows per band
-constexpr int IMG2_B = IMG2_ROWS * ROWB;   // 76 KiB
-constexpr float S_SCALE = 1.0f / 16.0f;    // coefficients are kept as S / 16 in fp16 (the synthesis basis carries the 16)
-
-struct ColsArgs {
-    const h16* T;  // [B*CG][H][jw][32]
-    h16* U[3];     // [B*CG][H][nw[k]][32]
-    const h16* pht;
-    const h16* b2[3];
-    int ld_b2[3];
-    int B, CG, H, jw, nw[3], nh, nhk[3], asym0[3], nasym[3];
-    float* pooled;
+struct AnaArgs {
+    View x;           // FROM_VIEW: bf16 source tensor; item = image row, k = pixel of the row
+    int ups, Ws;      // nearest-upsampled source: pixel (row >> ups, k >> ups), source row pitch Ws
+    const h16* src;   // otherwise fp16 rows of 32 channels at src + bcg * src_b + k * src_k + item * src_i
+    long src_b;
+    int src_k, src_i;
+    h16* dst;         // dst + bcg * dst_b + m * dst_m + item * dst_i
+    long dst_b;
+    int dst_m, dst_i;
+    const h16* basis; // fragment-major [pad32(M)][K]
+    int K, M, NB, CG, nitems;
+    float scale;
+    float* pooled;    // plane mean = DC coefficient * pool_scale (analysis along H only)
     int pooled_ld;
     float pool_scale;
 };
 
-__global__ __launch_bounds__(THREADS) void mf_cols(ColsArgs a) {
+template <bool FROM_VIEW>
+__global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
+    constexpr int G = 2, ROWB = 128, KS = 32;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* img2 = lds + 2 * IMG1_B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // M is a multiple of 32 (host).  Waves beyond the last basis tile repeat it (same values to the same addresses):
+    // with no predicate around the stores their number per group is a constant, which lets the compiler wait for the
+    // prefetched loads only (vmcnt = stores issued since) instead of draining the stores at the end of every group.
+    const int NT = a.M >> 5, nks = a.K >> 4;
+    const int tw = min(wave, NT - 1);
+    half8 bq[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        bq[ks] = ks < nks ? *(const half8*)(a.basis + ((size_t)(tw * nks + ks) * 64 + lane) * 8) : zero_h8();
     int ta[G][2];
 #pragma unroll
-    for (int mt = 0; mt < G; ++mt) {
-        ta[mt][0] = tr_addr(lane, mt, 0);
-        ta[mt][1] = tr_addr(lane, mt, 1);
+    for (int g = 0; g < G; ++g) {
+        ta[g][0] = tr_addr<G>(lane, g, 0);
+        ta[g][1] = tr_addr<G>(lane, g, 1);
     }
-    const int jgroups = (a.jw + G - 1) / G;
-    const int ngroups = a.B * a.CG * jgroups;
-    const int nch1 = (a.H + KC1 - 1) / KC1;
-    const int NT1 = (a.nh + 31) / 32, NT2 = a.H / 32;
-    // partner rows that no band writes must read as zero for ever
-    for (int i = tid; i < 48 * 16; i += THREADS) *(uint4*)(img2 + img_off(256 + (i >> 4), i & 15)) = make_uint4(0u, 0u, 0u, 0u);
-
-    const int ch16 = tid & 15, kk0 = tid >> 4;  // item i -> row kk0 + 32 i, 16-byte chunk ch16 (batch member ch16 >> 2)
-    auto fetch = [&](int grp, int chunk, uint4 (&pre)[4]) {
-        const int bcg = grp / jgroups, j0 = (grp % jgroups) * G;
-        const int j = j0 + (ch16 >> 2);
+    const int gpb = (a.nitems + G - 1) / G, ngroups = a.NB * gpb;
+    const int ch = tid & 7, r0 = tid >> 3, oct = ch & 3;  // loader: rows r0 + 64 i, 16-byte chunk ch (item ch >> 2)
+    auto fetch = [&](int grp, uint4 (&pre)[8]) {
+        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int item = min(i0 + (ch >> 2), a.nitems - 1);
+        if (FROM_VIEW) {
+            const int b = bcg / a.CG, cg = bcg - b * a.CG;
+            const bf16_t* xb = (const bf16_t*)a.x.p + (long)b * a.x.bs;
+            const unsigned rowpix = (unsigned)(item >> a.ups) * a.Ws;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = chunk * KC1 + kk0 + 32 * i;
-            pre[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (k < a.H && j < a.jw) pre[i] = *(const uint4*)(a.T + (((long)bcg * a.H + k) * a.jw + j) * 32 + (ch16 & 3) * 8);
+            for (int i = 0; i < 8; ++i) {
+                const int k = min(r0 + 64 * i, a.K - 1);
+                pre[i] = *(const uint4*)(xb + voff32(a.x, rowpix + (k >> a.ups), cg * 32 + oct * 8));
+            }
+        } else {
+            const h16* sb = a.src + (long)bcg * a.src_b + (long)item * a.src_i + oct * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 64 * i, a.K - 1) * a.src_k);
         }
     };
-    auto stash = [&](const uint4 (&pre)[4], char* img) {
+    auto stash = [&](const uint4 (&pre)[8], char* img) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(uint4*)(img + img_off(kk0 + 32 * i, ch16)) = pre[i];
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 64 * i;
+            if (row < a.K) *(uint4*)(img + img_off<G>(row, ch)) = FROM_VIEW ? bf16x8_to_h16x8(pre[i]) : pre[i];
+        }
     };
 
     int grp = blockIdx.x;
     if (grp >= ngroups) return;
-    uint4 pre[4];
-    fetch(grp, 0, pre);
-    __syncthreads();  // zero fill of the partner rows
+    uint4 pre[8];
+    fetch(grp, pre);
+    // rows K .. 511 of both images stay zero for ever: the k loop below always runs its 32 steps (a branch per k-step
+    // costs a copy of the accumulators at every join), the basis registers of the missing steps are zero as well
+    for (int i = tid; i < 2 * IMG_B / 16; i += THREADS) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
     stash(pre, lds);
     __syncthreads();
-    unsigned step = 0;
-    for (; grp < ngroups; grp += gridDim.x) {
-        const int bcg = grp / jgroups, j0 = (grp % jgroups) * G;
-        // ---- analysis along H -------------------------------------------------------------------------------
-        f32x16 acc1[G][1];
+    for (unsigned it = 0;; ++it) {
+        const int ngrp = grp + gridDim.x;
+        const bool more = ngrp < ngroups;
+        fetch(more ? ngrp : grp, pre);  // unconditional: a branch around a load drains the memory pipe at the join
+        asm volatile("" ::: "memory");  // the loads stay ahead of this group's stores
+        const char* img = lds + (it & 1) * IMG_B;
+        {
+            const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+            f32x16 acc[G];
 #pragma unroll
-        for (int mt = 0; mt < G; ++mt)
+            for (int g = 0; g < G; ++g) zero_acc(acc[g]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc1[mt][0][i] = 0.f;
-        const bool on1[1] = {wave < NT1};
-        bool more = true;
-        for (int c = 0; c < nch1; ++c) {
-            int ng = grp, nc = c + 1;
-            if (nc == nch1) {
-                nc = 0;
-                ng = grp + gridDim.x;
+            for (int ks = 0; ks < KS; ++ks) {
+                const char* base = img + ks * 16 * ROWB;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_read(base, ta[g][0], ta[g][1]), bq[ks], acc[g], 0, 0, 0);
             }
-            more = ng < ngroups;
-            if (more) fetch(ng, nc, pre);
-            const char* img = lds + (step & 1) * IMG1_B;
-            const int kc = min(a.H - c * KC1, KC1);
-            const h16* bptr[1] = {a.pht + ((size_t)(min(wave, NT1 - 1) * (a.H / 16) + c * (KC1 / 16)) * 64 + lane) * 8};
-            mma_steps<1, 4>(acc1, img, 0, (kc + 15) >> 4, bptr, ta);
-            if (c + 1 < nch1) {
-                stash(pre, lds + ((step + 1) & 1) * IMG1_B);
-                __syncthreads();
-                ++step;
-            }
-        }
-        // (the prefetched first chunk of the next group stays in `pre` until the synthesis below is done)
-        // ---- coefficients -> image 2 ---------------------------------------------------------------------------
-        if (on1[0]) {
-            const int n = wave * 32 + (lane & 31), hk = lane >> 5;
-            if (n < 256) {
+            const int m = tw * 32 + (lane & 31), hk = lane >> 5;
+            uint4 lo[G], hi[G];
 #pragma unroll
-                for (int mt = 0; mt < G; ++mt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint2 v;
-                        v.x = pack_h2(acc1[mt][0][4 * q] * S_SCALE, acc1[mt][0][4 * q + 1] * S_SCALE);
-                        v.y = pack_h2(acc1[mt][0][4 * q + 2] * S_SCALE, acc1[mt][0][4 * q + 3] * S_SCALE);
-                        *(uint2*)(img2 + img_off(n, mt * 4 + q) + 8 * hk) = v;
-                    }
-            }
-            // partner rows of the asymmetric mask rows: lane n = 2f (+1) feeds the sin (cos) slot of its frequency
-            const int f = n >> 1;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int idx = f - a.asym0[k];
-                if (idx < 0 || idx >= a.nasym[k]) continue;
-                const int row = 256 + 16 * k + 2 * idx + (1 - (n & 1));
-#pragma unroll
-                for (int mt = 0; mt < G; ++mt) {
-                    const bool dc = (j0 + mt) < 2;  // DC column (and its dummy): the reference averages the mask there
-                    const float sg = dc ? 0.f : ((((n ^ mt) & 1) == 0) ? S_SCALE : -S_SCALE);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint2 v;
-                        v.x = pack_h2(acc1[mt ^ 1][0][4 * q] * sg, acc1[mt ^ 1][0][4 * q + 1] * sg);
-                        v.y = pack_h2(acc1[mt ^ 1][0][4 * q + 2] * sg, acc1[mt ^ 1][0][4 * q + 3] * sg);
-                        *(uint2*)(img2 + img_off(row, mt * 4 + q) + 8 * hk) = v;
-                    }
-                }
-            }
-            if (a.pooled && j0 == 0 && n == 0) {  // mean = <x, q_0 p_0> / sqrt(HW)
-                const int b = bcg / a.CG, cg = bcg % a.CG;
+            for (int g = 0; g < G; ++g) tile_to_rows<false>(acc[g], a.scale, lo[g], hi[g]);
+            // The next image is staged BEFORE this group's stores are issued: the wait for the prefetched loads then has
+            // nothing younger than them in the memory pipe (the compiler cannot assume that loads return ahead of younger
+            // stores, it would drain every store here), and the stores drain under the next group's matrix phase.
+            if (more) stash(pre, lds + ((it + 1) & 1) * IMG_B);
+            asm volatile("" ::: "memory");
+            if (a.pooled && i0 == 0 && wave == 0 && m == 0) {  // mean = <x, q_0 p_0> / sqrt(HW)
+                const int b = bcg / a.CG, cg = bcg - b * a.CG;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    a.pooled[(long)b * a.pooled_ld + cg * 32 + (i & 3) + 8 * (i >> 2) + 4 * hk] = acc1[0][0][i] * a.pool_scale;
+                    a.pooled[(long)b * a.pooled_ld + cg * 32 + (i & 3) + 8 * (i >> 2) + 4 * hk] = acc[0][i] * a.pool_scale;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                uint4* d = (uint4*)(a.dst + (long)bcg * a.dst_b + (long)m * a.dst_m + (long)(i0 + g) * a.dst_i + hk * 16);
+                d[0] = lo[g];  // nitems is even (host): both items exist
+                d[1] = hi[g];
             }
         }
-        __syncthreads();  // image 2 complete; image-1 stage `step` consumed
-        // ---- synthesis along H, one band at a time --------------------------------------------------------------
-        const int n2[2] = {wave, wave + 8};
-        const bool on2[2] = {n2[0] < NT2, n2[1] < NT2};
-#pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
-            if (j0 >= a.nw[k]) continue;
-            f32x16 acc2[G][2];
+        if (!more) break;
+        __syncthreads();
+        grp = ngrp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// synthesis: out[item][m] = sum_k data[item][k] basis[m][k];  K <= 256, M <= 512: two 32-function basis tiles per
+// wave, four items per staged image (K rows x 256 bytes), three bands per item group
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WIN_ROWS = 32;                   // window rows per band (two k-steps)
+constexpr int WIN_B = 3 * WIN_ROWS * 256;      // 24 KiB
+struct SynArgs {
+    const h16* src[3];  // fp16 rows of 32 channels at src + bcg * src_b + k * src_k + item * src_i
+    long src_b[3];
+    int src_k[3], src_i[3];
+    int K[3];           // data rows of band k (SHARED: K[0] rows serve all bands)
+    int ksm[3];         // k-steps of band k taken straight from the staged image
+    int nwin[3];        // SHARED: window k-steps after them (0..2)
+    const float2* win;  // SHARED: [3][32] weights (s, d) of the window rows
+    h16* dst[3];        // SHARED: dst + bcg * dst_b + m * dst_m + item * dst_i
+    long dst_b[3];
+    int dst_m[3], dst_i[3];
+    View out[3];        // !SHARED: bf16 planes, pixel = item * Wout + m
+    int Wout;
+    int nitems[3];      // valid items of band k (nested, nitems[0] the largest)
+    int M, NB, CG;
+    const h16* basis;   // fragment-major [pad32(M)][16 * nks_tab]
+    int nks_tab;
+};
+
+// SHARED = true: synthesis along H (one staged coefficient image per item group, mask weights through the window rows,
+// fp16 out);  false: synthesis along W (one image per band, bf16 views out).
+template <bool SHARED>
+__global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
+    constexpr int G = 4, ROWB = 256, KS = 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* winimg = lds + 2 * IMG_B;
+    float2* wts = (float2*)(winimg + WIN_B);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // M is a multiple of 32 (host); tiles beyond the last one repeat it, items beyond the last one repeat it (the loader
+    // clamps the same way): no predicate around the stores, see mf_analysis
+    const int NT = a.M >> 5;
+    const int tj[2] = {min(2 * wave, NT - 1), min(2 * wave + 1, NT - 1)};
+    half8 bq[KS][2];
 #pragma unroll
-            for (int mt = 0; mt < G; ++mt)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
+            bq[ks][j] = ks < a.nks_tab ? *(const half8*)(a.basis + ((size_t)(tj[j] * a.nks_tab + ks) * 64 + lane) * 8) : zero_h8();
+    if (SHARED) {
+        if (tid < 3 * WIN_ROWS) wts[tid] = a.win[tid];
+    }
+    const int gpb = (a.nitems[0] + G - 1) / G, ngroups = a.NB * gpb;
+    // loader: rows r0 + 32 i, 16-byte chunk ch (item ch >> 2); tl = fresh_tid()
+    auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[8]) {
+        const int ch = tl & 15, r0 = tl >> 4, oct = ch & 3;
+        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
+        const int item = min(i0 + (ch >> 2), sel3(band, a.nitems[0], a.nitems[1], a.nitems[2]) - 1);
+        const h16* sb = sel3(band, a.src[0], a.src[1], a.src[2]) + (long)bcg * sel3(band, a.src_b[0], a.src_b[1], a.src_b[2]) +
+                        (long)item * sel3(band, a.src_i[0], a.src_i[1], a.src_i[2]) + oct * 8;
+        const int sk = sel3(band, a.src_k[0], a.src_k[1], a.src_k[2]);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc2[mt][j][i] = 0.f;
-            const int nks = (a.nhk[k] + 15) >> 4;
-            const h16* bptr[2];
+        for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 32 * i, K - 1) * sk);
+    };
+    // all 256 rows are written (zeros from row K on): the k loop always runs its 16 steps -- a branch per k-step costs a
+    // copy of the accumulators at every join -- and the basis registers are shared by bands of different K
+    auto stash = [&](int tl, const uint4 (&pre)[8], char* img, int band) {
+        const int ch = tl & 15, r0 = tl >> 4;
+        const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bptr[j] = a.b2[k] + ((size_t)(min(n2[j], NT2 - 1) * (a.ld_b2[k] / 16)) * 64 + lane) * 8;
-            mma_steps<2, 3>(acc2, img2, 0, nks, bptr, ta);
-            if (a.nasym[k] > 0) {
-                const h16* bx[2] = {bptr[0] + nks * FRAG, bptr[1] + nks * FRAG};
-                mma_steps<2, 1>(acc2, img2, 256 + 16 * k, 1, bx, ta);
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 32 * i;
+            *(uint4*)(img + img_off<G>(row, ch)) = row < K ? pre[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    int grp = blockIdx.x, band = 0;
+    if (grp >= ngroups) return;
+    uint4 pre[8];
+    fetch(tid, grp, 0, pre);
+    stash(tid, pre, lds, 0);
+    __syncthreads();
+    for (unsigned it = 0;; ++it) {
+        int ngrp = grp, nband = band + 1;
+        if (SHARED || nband == 3) {
+            nband = 0;
+            ngrp = grp + gridDim.x;
+        }
+        const bool more = ngrp < ngroups;
+        fetch(fresh_tid(wave), more ? ngrp : grp, more ? nband : band, pre);  // unconditional (see mf_analysis)
+        asm volatile("" ::: "memory");
+        const char* img = lds + (it & 1) * IMG_B;
+        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int b = bcg / a.CG, cg = bcg - b * a.CG;
+        const int hk = lane >> 5;
+
+        if (SHARED) {
+            // window rows of the three bands: s * own + (+-d) * partner (the other function of the frequency pair, taken
+            // from the partner column j ^ 1 = item ^ 1); thread -> (row tid >> 4, chunk tid & 15) of every band
+            const int tl = fresh_tid(wave);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = tl >> 4, ch = tl & 15;
+                const int n = 16 * a.ksm[k] + r;
+                const float2 w = wts[k * WIN_ROWS + r];
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (r < 16 * a.nwin[k] && n < a.K[0] && (w.x != 0.f || w.y != 0.f)) {
+                    const uint4 own = *(const uint4*)(img + img_off<G>(n, ch));
+                    const uint4 par = *(const uint4*)(img + img_off<G>(n ^ 1, ch ^ 4));
+                    const int mt = ch >> 2;
+                    const bool dc = i0 + mt < 2;  // DC column (and its dummy): the reference averages the mask there
+                    const float cp = dc ? 0.f : ((((n ^ mt) & 1) == 1) ? w.y : -w.y);
+                    const uint32_t o[4] = {own.x, own.y, own.z, own.w}, p[4] = {par.x, par.y, par.z, par.w};
+                    uint32_t q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float2 fo = __half22float2(*(const __half2*)&o[i]), fp = __half22float2(*(const __half2*)&p[i]);
+                        q[i] = pack_h2(w.x * fo.x + cp * fp.x, w.x * fo.y + cp * fp.y);
+                    }
+                    v = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+                if (r < 16 * a.nwin[k]) *(uint4*)(winimg + img_off<G>(k * WIN_ROWS + r, ch)) = v;
             }
+            __syncthreads();
+        }
+
+        {
+            bool staged = false;  // band 0 of a group always runs (i0 < nitems[0])
+#pragma unroll 1
+            for (int k = SHARED ? 0 : band; k < (SHARED ? 3 : band + 1); ++k) {
+                const int nit = sel3(k, a.nitems[0], a.nitems[1], a.nitems[2]);
+                if (i0 >= nit) continue;
+                const int ksm = sel3(k, a.ksm[0], a.ksm[1], a.ksm[2]);
+                const int kend = ksm + (SHARED ? sel3(k, a.nwin[0], a.nwin[1], a.nwin[2]) : 0);
+                const char* wbase = winimg + (k * WIN_ROWS - 16 * ksm) * ROWB;  // window row of k-step ks: k * 32 + 16 (ks - ksm)
+                auto store = [&](int g, int j, const uint4& lo, const uint4& hi) {
+                    // SHARED: the staged items are those of band 0, a narrower band drops the ones it does not have
+                    if (SHARED && i0 + g >= nit) return;
+                    const int ig = min(i0 + g, nit - 1), m = tj[j] * 32 + (lane & 31);
+                    uint4* d;
+                    if (SHARED) {
+                        d = (uint4*)(sel3(k, a.dst[0], a.dst[1], a.dst[2]) + (long)bcg * sel3(k, a.dst_b[0], a.dst_b[1], a.dst_b[2]) +
+                                     (long)m * sel3(k, a.dst_m[0], a.dst_m[1], a.dst_m[2]) +
+                                     (long)ig * sel3(k, a.dst_i[0], a.dst_i[1], a.dst_i[2]) + hk * 16);
+                    } else {
+                        const View o = sel3(k, a.out[0], a.out[1], a.out[2]);
+                        d = (uint4*)((bf16_t*)o.p + (long)b * o.bs + voff32(o, (unsigned)ig * a.Wout + m, cg * 32 + hk * 16));
+                    }
+                    d[0] = lo;
+                    d[1] = hi;
+                };
+                uint4 held[2][2][2];  // packed rows of items 0 and 1, kept until the next image has been staged
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (!on2[j]) continue;
-                const int m = n2[j] * 32 + (lane & 31);
+                for (int g = 0; g < G; ++g) {
+                    const int ta0 = tr_addr<G>(lane, g, 0), ta1 = tr_addr<G>(lane, g, 1);
+                    // k-steps 0 .. kend - 1: the loop leaves early instead of branching around every step (an exit edge
+                    // keeps the accumulators where they are, a skipped step costs a copy of them at the join)
+                    f32x16 acc[2];
 #pragma unroll
-                for (int mt = 0; mt < G; ++mt) {
-                    uint4 lo, hi;
-                    tile_to_rows<false>(acc2[mt][j], 1.0f, lo, hi);
-                    if (j0 + mt >= a.nw[k]) continue;
-                    uint4* dst = (uint4*)(a.U[k] + (((long)bcg * a.H + m) * a.nw[k] + j0 + mt) * 32 + (lane >> 5) * 16);
-                    dst[0] = lo;
-                    dst[1] = hi;
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (ks && ks >= kend) break;
+                        const char* base = img + ks * 16 * ROWB;
+                        if (SHARED) base = ks < ksm ? base : wbase + ks * 16 * ROWB;
+                        const half8 d = tr_read(base, ta0, ta1);
+                        if (ks == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][0], z, 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][1], z, 0, 0, 0);
+                        } else {
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][0], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][1], acc[1], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint4 lo, hi;
+                        tile_to_rows<!SHARED>(acc[j], 1.0f, lo, hi);
+                        if (g < 2) {
+                            held[g][j][0] = lo;
+                            held[g][j][1] = hi;
+                        } else {
+                            store(g, j, lo, hi);
+                        }
+                    }
+                    if (g == 1) {
+                        // stage the next image before the first store of this group goes out (see mf_analysis)
+                        if (!staged && more) stash(fresh_tid(wave), pre, lds + ((it + 1) & 1) * IMG_B, nband);
+                        staged = true;
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) store(gg, j, held[gg][j][0], held[gg][j][1]);
+                    }
                 }
             }
         }
-        if (more) stash(pre, lds + ((step + 1) & 1) * IMG1_B);
-        __syncthreads();  // next group's first chunk staged; image 2 free again
-        ++step;
+        if (!more) break;
+        __syncthreads();
+        grp = ngrp;
+        band = nband;
     }
 }
 
@@ -485,54 +527,62 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     if (jw > 256) return SR_OK;
     // y axis: symmetric / antisymmetric parts of each row mask
     std::vector<double> s(3 * (H / 2 + 1), 0.0), d(3 * (H / 2 + 1), 0.0);
-    int fmax[3], asym0[3], nasym[3];
+    int fmax[3];
     for (int k = 0; k < 3; ++k) {
         const unsigned char* rm = rows + k * H;
         if (rm[H / 2]) return SR_OK;  // Nyquist row kept: not representable
         fmax[k] = -1;
-        asym0[k] = 0;
-        nasym[k] = 0;
-        int last_asym = -1;
         for (int f = 0; f < H / 2; ++f) {
             const double mp = rm[f] ? 1.0 : 0.0, mn = rm[(H - f) % H] ? 1.0 : 0.0;
             s[k * (H / 2 + 1) + f] = f ? 0.5 * (mp + mn) : mp;
             d[k * (H / 2 + 1) + f] = f ? 0.5 * (mp - mn) : 0.0;
             if (mp + mn > 0) fmax[k] = f;
-            if (f && mp != mn) {
-                if (!nasym[k]) asym0[k] = f;
-                if (last_asym >= 0 && f != last_asym + 1) return SR_OK;  // must be one run
-                last_asym = f;
-                ++nasym[k];
-            }
         }
-        if (fmax[k] < 0 || nasym[k] > 8) return SR_OK;
+        if (fmax[k] < 0) return SR_OK;
         if (k && fmax[k] > fmax[k - 1]) return SR_OK;
     }
     const int nh = 2 * (fmax[0] + 1);
     if (nh > 256) return SR_OK;
-    pl->mf_jw = jw;
-    pl->mf_nh = nh;
+    // the kernels see both coefficient counts rounded up to whole basis tiles (the extra functions are zero)
+    pl->mf_jw = pad_to(jw, 32);
+    pl->mf_nh = pad_to(nh, 32);
+    // y weights per band: ones up to the first frequency with s < 1 (main k-steps), then a window of 32 rows
+    std::vector<float> win(3 * 32 * 2, 0.f);
     for (int k = 0; k < 3; ++k) {
         pl->mf_nw[k] = 2 * pl->half[k];
         pl->mf_nhk[k] = 2 * (fmax[k] + 1);
-        pl->mf_asym0[k] = asym0[k];
-        pl->mf_nasym[k] = nasym[k];
-        pl->mf_ld_b2[k] = pad_to(pl->mf_nhk[k], 16) + 16;
+        const double* sk = &s[k * (H / 2 + 1)];
+        const double* dk = &d[k * (H / 2 + 1)];
+        if (sk[0] != 1.0) return SR_OK;
+        int f1 = 0;
+        while (f1 < H / 2 && sk[f1] == 1.0) ++f1;
+        const int ksm = (2 * f1) >> 4;
+        int last = -1;
+        for (int f = 8 * ksm; f < H / 2; ++f) {
+            if (sk[f] == 0.0 && dk[f] == 0.0) continue;
+            const int r = 2 * f - 16 * ksm;
+            if (r + 1 >= 32 || 2 * f + 1 >= nh) return SR_OK;  // does not fit the window
+            win[(k * 32 + r) * 2] = win[(k * 32 + r + 1) * 2] = (float)sk[f];
+            win[(k * 32 + r) * 2 + 1] = win[(k * 32 + r + 1) * 2 + 1] = (float)dk[f];
+            last = r + 1;
+        }
+        pl->mf_ksm[k] = ksm;
+        pl->mf_nwin[k] = last < 0 ? 0 : (last >> 4) + 1;
+        if (ksm + pl->mf_nwin[k] > 16) return SR_OK;
     }
-    pl->mf_ld_qw = pad_to(jw, 16);
-    const size_t n_qwt = (size_t)pad_to(jw, 32) * W, n_qw = (size_t)W * pl->mf_ld_qw, n_pht = (size_t)pad_to(nh, 32) * H;
-    size_t n_b2[3], off = 0;
-    auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n * sizeof(h16), 256); return o; };
-    const size_t o_qwt = carve(n_qwt), o_qw = carve(n_qw), o_pht = carve(n_pht);
-    size_t o_b2[3];
-    for (int k = 0; k < 3; ++k) {
-        n_b2[k] = (size_t)H * pl->mf_ld_b2[k];
-        o_b2[k] = carve(n_b2[k]);
-    }
+    pl->mf_ld_qw = pad_to(jw, 32);
+    pl->mf_ld_ph = pad_to(nh, 32);
+    const size_t n_qwt = (size_t)pad_to(jw, 32) * W, n_qw = (size_t)pad_to(W, 32) * pl->mf_ld_qw, n_pht = (size_t)pad_to(nh, 32) * H,
+                 n_ph = (size_t)pad_to(H, 32) * pl->mf_ld_ph;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_qwt = carve(n_qwt * sizeof(h16)), o_qw = carve(n_qw * sizeof(h16)), o_pht = carve(n_pht * sizeof(h16)),
+                 o_ph = carve(n_ph * sizeof(h16)), o_win = carve(win.size() * sizeof(float));
     std::vector<char> host(off, 0);
     h16* qwt = (h16*)&host[o_qwt];
     h16* qw = (h16*)&host[o_qw];
     h16* pht = (h16*)&host[o_pht];
+    h16* ph = (h16*)&host[o_ph];
     for (int j = 0; j < jw; ++j)
         for (int w = 0; w < W; ++w) {
             const double v = basis_val(j, w, W);
@@ -540,21 +590,12 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
             qw[frag_index(w, j, pl->mf_ld_qw / 16)] = (h16)v;
         }
     for (int n = 0; n < nh; ++n)
-        for (int h = 0; h < H; ++h) pht[frag_index(n, h, H / 16)] = (h16)basis_val(n, h, H);
-    for (int k = 0; k < 3; ++k) {
-        h16* b2 = (h16*)&host[o_b2[k]];
-        const int ld = pl->mf_ld_b2[k], kx = pad_to(pl->mf_nhk[k], 16);
         for (int h = 0; h < H; ++h) {
-            for (int n = 0; n < pl->mf_nhk[k]; ++n) b2[frag_index(h, n, ld / 16)] = (h16)(16.0 * s[k * (H / 2 + 1) + (n >> 1)] * basis_val(n, h, H));
-            for (int i = 0; i < nasym[k]; ++i) {
-                const int f = asym0[k] + i;
-                const double df = d[k * (H / 2 + 1) + f];
-                // slot 2i pairs with the cos function (data: -/+ partner sin coefficient), slot 2i+1 with the sin function
-                b2[frag_index(h, kx + 2 * i, ld / 16)] = (h16)(16.0 * df * basis_val(2 * f, h, H));
-                b2[frag_index(h, kx + 2 * i + 1, ld / 16)] = (h16)(16.0 * df * basis_val(2 * f + 1, h, H));
-            }
+            const double v = basis_val(n, h, H);
+            pht[frag_index(n, h, H / 16)] = (h16)v;
+            ph[frag_index(h, n, pl->mf_ld_ph / 16)] = (h16)(16.0 * v);  // S is kept as S / 16 in fp16
         }
-    }
+    memcpy(&host[o_win], win.data(), win.size() * sizeof(float));
     char* dev = nullptr;
     SR_HIP(hipMalloc((void**)&dev, off));
     const hipError_t e = hipMemcpy(dev, host.data(), off, hipMemcpyHostToDevice);
@@ -566,7 +607,8 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     pl->mf_qwt = dev + o_qwt;
     pl->mf_qw = dev + o_qw;
     pl->mf_pht = dev + o_pht;
-    for (int k = 0; k < 3; ++k) pl->mf_b2[k] = dev + o_b2[k];
+    pl->mf_ph = dev + o_ph;
+    pl->mf_win = dev + o_win;
     pl->mf_ok = 1;
     return SR_OK;
 }
@@ -591,65 +633,105 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         SR_HIP(hipGetDevice(&dev));
         SR_HIP(hipDeviceGetAttribute(&g_mfma_cus, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const int CG = C / 32;
-    const long rows = (long)B * CG * H;
-    h16* T = (h16*)ws;
-    h16* U[3];
-    U[0] = T + rows * pl->mf_jw * 32;
-    U[1] = U[0] + rows * pl->mf_nw[0] * 32;
-    U[2] = U[1] + rows * pl->mf_nw[1] * 32;
+    const int CG = C / 32, NB = B * CG;
+    const int jw = pl->mf_jw, nh = pl->mf_nh;
+    h16* T = (h16*)ws;                      // [NB][H][jw][32]
+    h16* S = T + (size_t)NB * H * jw * 32;  // [NB][nh][jw][32]
+    h16* U[3];                              // [NB][H][nw[k]][32]
+    U[0] = S + (size_t)NB * nh * jw * 32;
+    U[1] = U[0] + (size_t)NB * H * pl->mf_nw[0] * 32;
+    U[2] = U[1] + (size_t)NB * H * pl->mf_nw[1] * 32;
+    if ((size_t)((char*)(U[2] + (size_t)NB * H * pl->mf_nw[2] * 32) - (char*)ws) > sr_fbm_workspace_bytes(pl, B, C)) return SR_NOT_ELIGIBLE;
+    auto grid_for = [&](long items, int G) { return (int)std::min<long>((long)NB * ((items + G - 1) / G), g_mfma_cus); };
+    const int lds_ana = 2 * IMG_B, lds_syn = 2 * IMG_B + WIN_B + 3 * WIN_ROWS * (int)sizeof(float2);
 
-    RowsArgs ra{};
-    ra.x = x;
-    ra.ups = ups;
-    ra.T = T;
-    ra.basis = (const h16*)pl->mf_qwt;
-    ra.nks = W / 16;
-    ra.B = B;
-    ra.CG = CG;
-    ra.H = H;
-    ra.W = W;
-    ra.jw = pl->mf_jw;
-    for (int k = 0; k < 3; ++k) ra.nw[k] = pl->mf_nw[k];
-    const int grid_rows = (int)std::min<long>(rows / G, 2L * g_mfma_cus);
-    SR_HIP(hipFuncSetAttribute((const void*)mf_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, IMG_B));
-    mf_rows<0><<<grid_rows, RTHREADS, IMG_B, st>>>(ra);
+    AnaArgs a1{};  // T = x Qw
+    a1.x = x;
+    a1.ups = ups;
+    a1.Ws = W >> ups;
+    a1.dst = T;
+    a1.dst_b = (long)H * jw * 32;
+    a1.dst_m = 32;
+    a1.dst_i = jw * 32;
+    a1.basis = (const h16*)pl->mf_qwt;
+    a1.K = W;
+    a1.M = jw;
+    a1.NB = NB;
+    a1.CG = CG;
+    a1.nitems = H;
+    a1.scale = 1.0f;
+    SR_HIP(hipFuncSetAttribute((const void*)mf_analysis<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ana));
+    mf_analysis<true><<<grid_for(H, 2), THREADS, lds_ana, st>>>(a1);
     SR_LAUNCH_CHECK();
 
-    ColsArgs ca{};
-    ca.T = T;
-    ca.pht = (const h16*)pl->mf_pht;
-    ca.B = B;
-    ca.CG = CG;
-    ca.H = H;
-    ca.jw = pl->mf_jw;
-    ca.nh = pl->mf_nh;
+    AnaArgs a2{};  // S = Ph^T T / 16
+    a2.src = T;
+    a2.src_b = (long)H * jw * 32;
+    a2.src_k = jw * 32;
+    a2.src_i = 32;
+    a2.dst = S;
+    a2.dst_b = (long)nh * jw * 32;
+    a2.dst_m = jw * 32;
+    a2.dst_i = 32;
+    a2.basis = (const h16*)pl->mf_pht;
+    a2.K = H;
+    a2.M = nh;
+    a2.NB = NB;
+    a2.CG = CG;
+    a2.nitems = jw;
+    a2.scale = 1.0f / 16.0f;
+    a2.pooled = pooled;
+    a2.pooled_ld = pooled_ld;
+    a2.pool_scale = 1.0f / std::sqrt((float)H * (float)W);
+    SR_HIP(hipFuncSetAttribute((const void*)mf_analysis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ana));
+    mf_analysis<false><<<grid_for(jw, 2), THREADS, lds_ana, st>>>(a2);
+    SR_LAUNCH_CHECK();
+
+    SynArgs s3{};  // U_k = P (weights_k S)
     for (int k = 0; k < 3; ++k) {
-        ca.U[k] = U[k];
-        ca.b2[k] = (const h16*)pl->mf_b2[k];
-        ca.ld_b2[k] = pl->mf_ld_b2[k];
-        ca.nw[k] = pl->mf_nw[k];
-        ca.nhk[k] = pl->mf_nhk[k];
-        ca.asym0[k] = pl->mf_asym0[k];
-        ca.nasym[k] = pl->mf_nasym[k];
+        s3.src[k] = S;
+        s3.src_b[k] = (long)nh * jw * 32;
+        s3.src_k[k] = jw * 32;
+        s3.src_i[k] = 32;
+        s3.K[k] = nh;
+        s3.ksm[k] = pl->mf_ksm[k];
+        s3.nwin[k] = pl->mf_nwin[k];
+        s3.dst[k] = U[k];
+        s3.dst_b[k] = (long)H * pl->mf_nw[k] * 32;
+        s3.dst_m[k] = pl->mf_nw[k] * 32;
+        s3.dst_i[k] = 32;
+        s3.nitems[k] = pl->mf_nw[k];
     }
-    ca.pooled = pooled;
-    ca.pooled_ld = pooled_ld;
-    ca.pool_scale = 1.0f / std::sqrt((float)H * (float)W);
-    const long cgroups = (long)B * CG * ((pl->mf_jw + G - 1) / G);
-    const int lds_cols = 2 * IMG1_B + IMG2_B;
-    SR_HIP(hipFuncSetAttribute((const void*)mf_cols, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cols));
-    mf_cols<<<(int)std::min<long>(cgroups, g_mfma_cus), THREADS, lds_cols, st>>>(ca);
+    s3.win = (const float2*)pl->mf_win;
+    s3.M = H;
+    s3.NB = NB;
+    s3.CG = CG;
+    s3.basis = (const h16*)pl->mf_ph;
+    s3.nks_tab = pl->mf_ld_ph / 16;
+    SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_syn));
+    mf_synthesis<true><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
     SR_LAUNCH_CHECK();
 
-    ra.basis = (const h16*)pl->mf_qw;
-    ra.nks = pl->mf_ld_qw / 16;
-    ra.out[0] = l2;
-    ra.out[1] = l4;
-    ra.out[2] = l8;
-    for (int k = 0; k < 3; ++k) ra.U[k] = U[k];
-    SR_HIP(hipFuncSetAttribute((const void*)mf_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, IMG_B));
-    mf_rows<2><<<grid_rows, RTHREADS, IMG_B, st>>>(ra);
+    SynArgs s4{};  // L_k = U_k Qw_k^T
+    const View outs[3] = {l2, l4, l8};
+    for (int k = 0; k < 3; ++k) {
+        s4.src[k] = U[k];
+        s4.src_b[k] = (long)H * pl->mf_nw[k] * 32;
+        s4.src_k[k] = 32;
+        s4.src_i[k] = pl->mf_nw[k] * 32;
+        s4.K[k] = pl->mf_nw[k];
+        s4.ksm[k] = (pl->mf_nw[k] + 15) / 16;
+        s4.out[k] = outs[k];
+        s4.nitems[k] = H;
+    }
+    s4.Wout = W;
+    s4.M = W;
+    s4.NB = NB;
+    s4.CG = CG;
+    s4.basis = (const h16*)pl->mf_qw;
+    s4.nks_tab = pl->mf_ld_qw / 16;
+    SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_syn));
+    mf_synthesis<false><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

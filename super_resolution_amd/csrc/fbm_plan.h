@@ -25,13 +25,15 @@ struct sr_fbm_plan {
     int mf_nw[3];          // prefix of them kept by mask k
     int mf_nh;             // y-basis functions with non-zero weight in mask k=2 (same ordering)
     int mf_nhk[3];         // prefix with non-zero symmetric weight per mask
-    int mf_ld_qw, mf_ld_b2[3];
-    void* mf_block;        // one device allocation: the four tables below (fp16)
-    void* mf_qwt;          // [pad32(jw)][W]      q_j[w]           rows forward
-    void* mf_qw;           // [W][pad16(jw)]      q_j[w]           rows inverse (band k uses the first nw[k] columns)
-    void* mf_pht;          // [pad32(nh)][H]      p_n[h]           columns forward
-    void* mf_b2[3];        // [H][pad16(nhk)+16]  16 s_n p_n[h'] ++ 16 d_f p(h') for the asymmetric rows of mask k
-    int mf_asym0[3], mf_nasym[3];  // first asymmetric y-frequency of mask k and how many (<= 8)
+    int mf_ld_qw, mf_ld_ph; // padded k extents (multiples of 16) of the two synthesis tables
+    void* mf_block;        // one device allocation: the tables below
+    void* mf_qwt;          // fp16 [pad32(jw)][W]      q_j[w]        analysis along W
+    void* mf_qw;           // fp16 [pad32(W)][pad16(jw)] q_j[w]      synthesis along W (band k uses the first nw[k] functions)
+    void* mf_pht;          // fp16 [pad32(nh)][H]      p_n[h]        analysis along H
+    void* mf_ph;           // fp16 [pad32(H)][pad16(nh)] 16 p_n[h]   synthesis along H (shared by the three bands)
+    void* mf_win;          // float2 [3][32]: (s, d) weights of the 32 y-coefficient rows after the main k-steps of band k
+    int mf_ksm[3];         // main k-steps of band k: y-coefficients 0 .. 16 * ksm - 1 enter with weight one
+    int mf_nwin[3];        // window k-steps after them (0..2)
 };
 
 namespace sr {

@@ -106,7 +106,16 @@ def test_pack_unpack_and_pixel_unshuffle(L):
 
 # ------------------------------------------------------------------------------------------ FBM
 def run_lowpass(L, x, dt, ups=0):
+    """FFT kernels (generic and power-of-two); the DFT-as-GEMM path has its own test below."""
     lib = L.lib()
+    lib.sr_debug_force_fft_lowpass(1)
+    try:
+        return _run_lowpass(L, lib, x, dt, ups)
+    finally:
+        lib.sr_debug_force_fft_lowpass(-1)
+
+
+def _run_lowpass(L, lib, x, dt, ups):
     B, Cc, H, W = x.shape
     Ho, Wo = H << ups, W << ups
     plan = C.c_void_p()
@@ -167,8 +176,8 @@ def test_fbm_lowpass_pow2_upsampled_bf16(L):
 @pytest.mark.parametrize('shape,ups,cb', [((2, 32, 64, 96), 0, 0), ((1, 64, 128, 64), 0, 32), ((1, 32, 512, 128), 0, 32),
                                           ((1, 32, 96, 160), 0, 0), ((2, 64, 32, 48), 1, 32), ((1, 32, 256, 512), 0, 32)])
 def test_fbm_lowpass_mfma_bf16(L, shape, ups, cb):
-    """The opt-in DFT-as-GEMM path (fp16 MFMA, fbm_mfma.hip) for bf16 planes of 32-channel groups: against the oracle
-    (asymmetric row masks at H = 96, 128, 256, 512 included) and against the default FFT path on the same input."""
+    """The DFT-as-GEMM path (fp16 MFMA, fbm_mfma.hip; the default for bf16 planes of 32-channel groups) against the oracle
+    (asymmetric row masks at H = 96, 128, 256, 512 included) and against the FFT path on the same input."""
     lib = L.lib()
     x = bf(torch.from_numpy(gp.signed_input(shape, 23)))
     B, Cc, H, W = x.shape
@@ -194,7 +203,7 @@ def test_fbm_lowpass_mfma_bf16(L, shape, ups, cb):
                                        ws.data_ptr(), ws.numel(), st(L)))
             torch.cuda.synchronize()
         finally:
-            lib.sr_debug_force_fft_lowpass(1)
+            lib.sr_debug_force_fft_lowpass(-1)
         res.append(([back(b_) for b_ in bands], pooled.cpu()))
     lib.sr_fbm_plan_destroy(plan)
     xu = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x

@@ -45,7 +45,7 @@ def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0, force_fft=1):
                                    ws.data_ptr(), ws.numel(), st))
     t = timeit(run, reps)
     px = B * H * W * Cc
-    lib.sr_debug_force_fft_lowpass(1)
+    lib.sr_debug_force_fft_lowpass(-1)
     print('lowpass C=%d %dx%d B=%d blocked=%d fft=%d: %.1f us  (%.2f B/px/ch algorithmic 8 -> %.2f TB/s)' %
           (Cc, H, W, B, blocked, force_fft, t * 1e6, 8.0, px * 8 / t / 1e12))
 
