@@ -327,6 +327,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         return;
     }
     unsigned step = 0;
+    float* bias_lds = (float*)(lds + 2 * STAGE);  // [cout], zeros without a bias
+    for (int i = tid; i < cout; i += 256) bias_lds[i] = ep.bias ? ep.bias[i] : 0.f;
     __syncthreads();  // stage 0 is full
     for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
         const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
@@ -390,7 +392,6 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                     y[8 + j] = __uint_as_float(s1[0]);
                     y[12 + j] = __uint_as_float(s1[1]);
                 }
-                const int cb = o_blk + m * 32 + hk * 16;
                 if (cout < 32) {  // thin tail (conv_last: 1 or 3 channels): channel-wise epilogue from the low lanes
                     if (inside && hk == 0 && m == 0) {
 #pragma unroll
@@ -400,42 +401,64 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                     }
                     continue;
                 }
-                if (!inside || cb >= cout) continue;
+                // bias (staged in LDS once per workgroup) + activation, written back over the accumulators
+                const float* bl = bias_lds + o_blk + m * 32 + hk * 16;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) y[j] += ep.bias ? ep.bias[cb + j] : 0.f;
-                if (ep.lrelu) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) y[j] = lrelu02(y[j]);
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float* yh = y + 8 * half;
-                    if (ep.r1.p) {
-                        const uint4 rr = *(const uint4*)((const bf16_t*)ep.r1.p + voff(ep.r1, b, pix, cb + 8 * half));
-                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            yh[2 * j] = yh[2 * j] * ep.s1 + lo_f(rw[j]);
-                            yh[2 * j + 1] = yh[2 * j + 1] * ep.s1 + hi_f(rw[j]);
-                        }
-                    }
-                    if (ep.r2.p) {
-                        const uint4 rr = *(const uint4*)((const bf16_t*)ep.r2.p + voff(ep.r2, b, pix, cb + 8 * half));
-                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            yh[2 * j] = yh[2 * j] * ep.s2 + lo_f(rw[j]);
-                            yh[2 * j + 1] = yh[2 * j + 1] * ep.s2 + hi_f(rw[j]);
-                        }
-                    }
-                    uint4 st;
-                    st.x = pack2(yh[0], yh[1]);
-                    st.y = pack2(yh[2], yh[3]);
-                    st.z = pack2(yh[4], yh[5]);
-                    st.w = pack2(yh[6], yh[7]);
-                    *(uint4*)((bf16_t*)out.p + voff(out, b, pix, cb + 8 * half)) = st;
+                for (int j = 0; j < 16; ++j) {
+                    const float v = y[j] + bl[j];
+                    acc[m][n][j] = ep.lrelu ? lrelu02(v) : v;
                 }
             }
+        }
+        if (cout < 32) continue;
+        // Residuals: all loads of one residual are issued together and folded into the accumulators before the first
+        // store of the tile goes out.  (Loading them piecewise between the stores -- and the bias from global memory
+        // per 32x32 block -- made every piece wait for the stores before it to drain: 8 us per tile without and 21 us
+        // with residuals at Cout = 64, none of it hidden behind the loaders.)
+        auto fold = [&](const View& rv, float sc) {
+            uint4 rr[MT][4][2];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const long pix = (long)min(h0 + wave * 4 + n, H - 1) * W + min(w, W - 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        rr[m][n][half] = *(const uint4*)((const bf16_t*)rv.p + voff(rv, b, pix, o_blk + m * 32 + hk * 16 + 8 * half));
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const uint32_t rw[4] = {rr[m][n][half].x, rr[m][n][half].y, rr[m][n][half].z, rr[m][n][half].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[m][n][8 * half + 2 * j] = acc[m][n][8 * half + 2 * j] * sc + lo_f(rw[j]);
+                            acc[m][n][8 * half + 2 * j + 1] = acc[m][n][8 * half + 2 * j + 1] * sc + hi_f(rw[j]);
+                        }
+                    }
+        };
+        if (ep.r1.p) fold(ep.r1, ep.s1);
+        if (ep.r2.p) fold(ep.r2, ep.s2);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int h = h0 + wave * 4 + n;
+            if (h >= H || w >= W) continue;
+            const long pix = (long)h * W + w;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int o = 8 * half;
+                    uint4 st;
+                    st.x = pack2(acc[m][n][o], acc[m][n][o + 1]);
+                    st.y = pack2(acc[m][n][o + 2], acc[m][n][o + 3]);
+                    st.z = pack2(acc[m][n][o + 4], acc[m][n][o + 5]);
+                    st.w = pack2(acc[m][n][o + 6], acc[m][n][o + 7]);
+                    *(uint4*)((bf16_t*)out.p + voff(out, b, pix, o_blk + m * 32 + hk * 16 + 8 * half)) = st;
+                }
         }
     }
 }
@@ -463,12 +486,13 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
 template <int MT, bool BANDS>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
-    const size_t ldsb = 2 * ((size_t)NPIX * 64 + 9ul * MT * 32 * 64);
-    static bool attr_set = false;
-    if (!attr_set) {
+    const size_t ldsb = 2 * ((size_t)NPIX * 64 + 9ul * MT * 32 * 64) + (size_t)cout * sizeof(float);  // stages + bias
+    if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
+    static size_t attr_set = 0;
+    if (attr_set < ldsb) {
         SR_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_bf16<MT, BANDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)ldsb));
-        attr_set = true;
+        attr_set = ldsb;
     }
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
