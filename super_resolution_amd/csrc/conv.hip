@@ -177,7 +177,7 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
     // ---- haloed pixel tile: 612 pixels x 4 slots of 8 channels ---------------------------------------
     // G items per thread are fetched before any is consumed: the loaders are the only waves with loads in
     // flight on this CU, so each must keep ~20 x 16 B outstanding to cover the HBM latency.
-    constexpr int G = BANDS ? 4 : 10;
+    constexpr int G = BANDS ? 2 : 5;
     const View v2 = in.l2[cur.s], v4 = in.l4[cur.s], v8 = in.l8[cur.s];
     const bf16_t* b2 = BANDS ? (const bf16_t*)v2.p + (long)b * v2.bs : nullptr;
     const bf16_t* b4 = BANDS ? (const bf16_t*)v4.p + (long)b * v4.bs : nullptr;
@@ -197,47 +197,68 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
         wv[g] = *(const uint4*)(wb + ((long)tapc * cout + oc) * cin + cur.kc + chunk * 8);
         if (o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
     }
-    for (int it0 = ltid; it0 < NPIX * 4; it0 += 256 * G) {
-        uint4 vx_[G], a2[G], a4[G], a8[G];
+    // Rounds of G items per thread, software-pipelined two deep: round r + 1 is in flight while round r is modulated
+    // and written to LDS, so the memory pipe never runs dry between rounds (the loaders are the only waves of the CU
+    // with global loads in flight, and they never store: the compiler can count their loads exactly).
+    constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
+    struct Batch {
+        uint4 vx[G], a2[G], a4[G], a8[G];
         float4 gg[G];
-        int dst[G];
-        bool ok[G];
+    };
+    auto locate = [&](int it, int& chunk, int& pi, int& h, int& w) {
+        if (blocked) {  // a channel block's pixels are contiguous: pixels fastest
+            chunk = it / NPIX;
+            pi = it - chunk * NPIX;
+        } else {  // NHWC: the 4 slots of a pixel are contiguous
+            chunk = it & 3;
+            pi = it >> 2;
+        }
+        const int py = pi / PW, px = pi - py * PW;
+        h = h0 + py - 1;
+        w = w0 + px - 1;
+    };
+    auto issue = [&](int r, Batch& bt) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int it = it0 + g * 256;
-            int chunk, pi;
-            if (blocked) {  // a channel block's pixels are contiguous: pixels fastest
-                chunk = it / NPIX;
-                pi = it - chunk * NPIX;
-            } else {  // NHWC: the 4 slots of a pixel are contiguous
-                chunk = it & 3;
-                pi = it >> 2;
-            }
-            const int py = pi / PW, px = pi - py * PW;
-            const int h = h0 + py - 1, w = w0 + px - 1;
-            ok[g] = it < NPIX * 4 && h >= 0 && h < H && w >= 0 && w < W;
-            dst[g] = it < NPIX * 4 ? swz(pi, chunk) : -1;
+            int chunk, pi, h, w;
+            locate(ltid + (r * G + g) * 256, chunk, pi, h, w);
             // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards:
             // a branch around a load makes hipcc drain the memory pipeline per element
             const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
             const int ch = cur.cc + (chunk & 3) * 8;
             const unsigned ps = (unsigned)(hc >> in.ups) * Ws + (wc >> in.ups);
-            vx_[g] = *(const uint4*)(xb + voff32(vx, ps, ch));
+            bt.vx[g] = *(const uint4*)(xb + voff32(vx, ps, ch));
             if (BANDS) {
                 const unsigned p = (unsigned)hc * W + wc;
-                a2[g] = *(const uint4*)(b2 + voff32(v2, p, ch));
-                a4[g] = *(const uint4*)(b4 + voff32(v4, p, ch));
-                a8[g] = *(const uint4*)(b8 + voff32(v8, p, ch));
-                gg[g] = gb[p];
+                bt.a2[g] = *(const uint4*)(b2 + voff32(v2, p, ch));
+                bt.a4[g] = *(const uint4*)(b4 + voff32(v4, p, ch));
+                bt.a8[g] = *(const uint4*)(b8 + voff32(v8, p, ch));
+                bt.gg[g] = gb[p];
             }
         }
+    };
+    auto consume = [&](int r, const Batch& bt) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            uint4 v = vx_[g];
-            if (BANDS) v = modulate8(v, a2[g], a4[g], a8[g], gg[g].x, gg[g].y - gg[g].x, gg[g].z - gg[g].y, 1.0f - gg[g].z);
-            if (!ok[g]) v = make_uint4(0u, 0u, 0u, 0u);
-            if (dst[g] >= 0) *(uint4*)(lds_px + dst[g]) = v;
+            const int it = ltid + (r * G + g) * 256;
+            int chunk, pi, h, w;
+            locate(it, chunk, pi, h, w);
+            uint4 v = bt.vx[g];
+            if (BANDS) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
+            if (!(h >= 0 && h < H && w >= 0 && w < W)) v = make_uint4(0u, 0u, 0u, 0u);
+            if (it < NPIX * 4) *(uint4*)(lds_px + swz(pi, chunk)) = v;
         }
+    };
+    Batch bt0, bt1;
+    issue(0, bt0);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r + 1 < ROUNDS) {
+            if (r & 1) issue(r + 1, bt0);
+            else issue(r + 1, bt1);
+        }
+        if (r & 1) consume(r, bt1);
+        else consume(r, bt0);
     }
     // ---- weight slab (fetched first, see above) ---------------------------------------------------------
 #pragma unroll
