@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
 // 27 x C weight slice); per consumer the T image goes through the same LDS buffer and the 9-tap sum is added to the
 // consumer's logits (or finished as 2*sigmoid into the gates buffer).
 // ---------------------------------------------------------------------------------------------
+template <int NC>
 __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H, int W, GateConsList cl) {
     extern __shared__ __attribute__((aligned(16))) char glds[];
     float* T = (float*)glds;                                  // [GNT*32][27]
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
     const unsigned tiles = (unsigned)tilesx * ((H + GMH - 1) / GMH);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hk = lane >> 5;
-    for (int ci = 0; ci < cl.n; ++ci) {
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
         const float* w0 = cl.c[ci].w[0];
         const float* w1 = cl.c[ci].w[1];
         const float* w2 = cl.c[ci].w[2];
@@ -252,7 +254,14 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
         }
         const int ty = tid / GMW, tx = tid % GMW;
         const int h = h0 + ty, w = w0p + tx;
-        for (int ci = 0; ci < cl.n; ++ci) {
+        // running logits of every consumer, fetched together with the fragments (unconditional, clamped: a load behind
+        // a branch, or issued after the previous consumer's store, waits for the memory pipe to drain)
+        const long pix = ((long)b * H + min(h, H - 1)) * W + min(w, W - 1);
+        float4 lgp[NC];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) lgp[ci] = ((const float4*)(cl.c[ci].first ? cl.c[ci].gates ? (const float*)cl.c[ci].gates : cl.c[ci].logits : cl.c[ci].logits))[pix];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
             __syncthreads();  // weights staged / T of the previous consumer (or tile) consumed
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -276,18 +285,10 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
             __syncthreads();
             if (h < H && w < W) {
                 const GateCons& gc = cl.c[ci];
-                const long pix = ((long)b * H + h) * W + w;
                 float lg[3];
-                if (gc.first) {
-                    lg[0] = gc.b[0][0];
-                    lg[1] = gc.b[1][0];
-                    lg[2] = gc.b[2][0];
-                } else {
-                    const float4 p = ((const float4*)gc.logits)[pix];
-                    lg[0] = p.x;
-                    lg[1] = p.y;
-                    lg[2] = p.z;
-                }
+                lg[0] = gc.first ? gc.b[0][0] : lgp[ci].x;
+                lg[1] = gc.first ? gc.b[1][0] : lgp[ci].y;
+                lg[2] = gc.first ? gc.b[2][0] : lgp[ci].z;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const float* t = T + ((ty + tap / 3) * GPW + tx + tap % 3) * GTROW + tap * 3;
@@ -315,7 +316,6 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
     if (cl.n < 1 || cl.n > SR_MAX_GATE_CONSUMERS) return SR_ERR_ARG;
     if (seg.C % 16 || seg.C > 64 || !view_vec_ok(seg, 8)) return SR_NOT_ELIGIBLE;
     const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + (size_t)cl.n * 32 * (seg.C * 2 + 16);
-    SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_acc_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     static int ncu = 0;
@@ -325,7 +325,16 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
         SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const long per_cu = std::max<long>(1, std::min<long>(4, (160 * 1024) / (long)lds));
-    fbm_gates_acc_mfma<<<dim3((unsigned)std::min<long>(nblk, per_cu * ncu)), 256, lds, st>>>(seg, B, H, W, cl);
+    const dim3 grid((unsigned)std::min<long>(nblk, per_cu * ncu));
+#define SR_GATES_ACC(NC)                                                                                                 \
+    case NC:                                                                                                             \
+        SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_acc_mfma<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        fbm_gates_acc_mfma<NC><<<grid, 256, lds, st>>>(seg, B, H, W, cl);                                                  \
+        break;
+    switch (cl.n) {
+        SR_GATES_ACC(1) SR_GATES_ACC(2) SR_GATES_ACC(3) SR_GATES_ACC(4) SR_GATES_ACC(5) SR_GATES_ACC(6) SR_GATES_ACC(7) SR_GATES_ACC(8)
+    }
+#undef SR_GATES_ACC
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
