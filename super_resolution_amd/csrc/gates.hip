@@ -259,7 +259,12 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
         const long pix = ((long)b * H + min(h, H - 1)) * W + min(w, W - 1);
         float4 lgp[NC];
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) lgp[ci] = ((const float4*)(cl.c[ci].first ? cl.c[ci].gates ? (const float*)cl.c[ci].gates : cl.c[ci].logits : cl.c[ci].logits))[pix];
+        for (int ci = 0; ci < NC; ++ci) {
+            // a consumer that starts from its bias reads (and ignores) 16 bytes of the segment itself: cached, always valid
+            const char* src = cl.c[ci].first ? (const char*)((const bf16_t*)seg.p + voff(seg, b, pix - (long)b * H * W, 0))
+                                             : (const char*)(cl.c[ci].logits + 4 * pix);
+            lgp[ci] = *(const float4*)src;
+        }
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             __syncthreads();  // weights staged / T of the previous consumer (or tile) consumed

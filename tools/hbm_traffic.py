@@ -10,7 +10,7 @@ import glob
 import json
 import sys
 
-GROUPS = (('conv', ('conv3x3',)), ('lowpass', ('rows_fwd', 'rows_inv', 'cols', 'fft', 'mf_rows', 'mf_cols')),
+GROUPS = (('conv', ('conv3x3',)), ('lowpass', ('rows_fwd', 'rows_inv', 'cols', 'fft', 'mf_rows', 'mf_cols', 'mf_analysis', 'mf_synthesis')),
           ('gates', ('gates',)), ('weightgen', ('weightgen',)))
 
 
