@@ -22,8 +22,12 @@ from torch.nn import functional as F
 class RealESRGANer():
 
     def __init__(self, scale, model_path, dni_weight=None, model=None, tile=0, tile_pad=10, pre_pad=10, half=False,
-                 device=None, gpu_id=None, shard_tiles=False):
+                 device=None, gpu_id=None, shard_tiles=False, tile_batch=8):
+        """The reference signature (utils.py:29-40) plus two keyword extensions: `shard_tiles` deals the tiles over the
+        ranks of an initialised process group, `tile_batch` runs up to that many tiles of equal window size through the
+        network in one batch (every statistic of the network is per sample, so the result is the one-by-one result)."""
         self.scale = scale
+        self.tile_batch = max(1, int(tile_batch))
         self.tile_size = tile
         self.tile_pad = tile_pad
         self.pre_pad = pre_pad
@@ -113,6 +117,27 @@ class RealESRGANer():
             out = self.model(self.img[:, :, py0:py1, px0:px1])
         return out[:, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s]
 
+    def _run_tiles(self, wins, idxs):
+        """{tile index: output core} for the tiles `idxs`; tiles with equal window size share batches of `tile_batch`."""
+        groups = {}
+        for i in idxs:
+            (py0, py1, px0, px1) = wins[i][0]
+            groups.setdefault((py1 - py0, px1 - px0), []).append(i)
+        s, nb, done = self.scale, self.img.shape[0], {}
+        for members in groups.values():
+            for k in range(0, len(members), self.tile_batch):
+                part = members[k:k + self.tile_batch]
+                if len(part) == 1:
+                    done[part[0]] = self._run_tile(wins[part[0]])
+                    continue
+                crops = torch.cat([self.img[:, :, wins[i][0][0]:wins[i][0][1], wins[i][0][2]:wins[i][0][3]] for i in part], 0)
+                with torch.no_grad():
+                    out = self.model(crops)
+                for j, i in enumerate(part):
+                    (y0, y1, x0, x1), (oy, ox) = wins[i][1], wins[i][2]
+                    done[i] = out[j * nb:(j + 1) * nb, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s]
+        return done
+
     def tile_process(self):
         """Crop overlapping tiles, run each, paste the un-padded centres (utils.py:117-180)."""
         batch, channel, height, width = self.img.shape
@@ -122,13 +147,13 @@ class RealESRGANer():
         import torch.distributed as dist
         world = dist.get_world_size() if (self.shard_tiles and dist.is_available() and dist.is_initialized()) else 1
         if world == 1:
-            for win in wins:
-                (y0, y1, x0, x1) = win[1]
-                self.output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = self._run_tile(win)
+            for i, t in self._run_tiles(wins, range(len(wins))).items():
+                (y0, y1, x0, x1) = wins[i][1]
+                self.output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = t
             return
         rank = dist.get_rank()
         mine = self.shard_of(wins, rank, world)
-        done = {i: self._run_tile(wins[i]).contiguous() for i in mine}
+        done = {i: t.contiguous() for i, t in self._run_tiles(wins, mine).items()}
         if rank == 0:
             for i, t in done.items():
                 (y0, y1, x0, x1) = wins[i][1]

@@ -151,3 +151,29 @@ def test_tile_windows_and_sharding():
     out, mode = r.enhance((img * 255).astype(np.uint8))
     assert mode == 'RGB' and out.shape == (148, 212, 3)
     assert np.array_equal(out, np.repeat(np.repeat((img * 255).astype(np.uint8), 4, 0), 4, 1))
+
+
+def test_tile_batching_equals_one_by_one():
+    """tile_batch > 1 stacks tiles of equal window size along the batch axis: same result as one tile at a time for a
+    network whose statistics are per sample (here: a conv plus a per-sample mean, like FDConv's pooled attention)."""
+    from super_resolution_amd import RealESRGANer
+
+    class PerSample(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.conv = torch.nn.Conv2d(3, 3, 3, 1, 1)
+
+        def forward(self, x):
+            y = self.conv(x) * (1.0 + x.mean(dim=(1, 2, 3), keepdim=True))
+            return torch.nn.functional.interpolate(y, scale_factor=4, mode='nearest')
+
+    img = (gp.image_input((70, 90, 3), 9) * 255).astype(np.uint8)
+    outs = []
+    for tb in (1, 4):
+        r = RealESRGANer(scale=4, model_path=None, model=PerSample(), tile=16, tile_pad=4, pre_pad=0, device=torch.device('cpu'),
+                         tile_batch=tb)
+        outs.append(r.enhance(img)[0])
+    # torch's CPU conv picks its algorithm by batch size: allow one uint8 step of rounding difference
+    assert np.abs(outs[0].astype(np.int32) - outs[1].astype(np.int32)).max() <= 1
+    assert (outs[0] != outs[1]).mean() < 1e-3
