@@ -339,11 +339,13 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
     if (SHARED) {
         if (tid < 3 * WIN_ROWS) wts[tid] = a.win[tid];
     }
+    // SHARED: the narrower bands exist for the first item groups only (3, 2 or 1 bands of work per group); with the sample
+    // index fastest a workgroup's groups (grp = blockIdx + n * gridDim) are spread over the whole item range
     const int gpb = (a.nitems[0] + G - 1) / G, ngroups = a.NB * gpb;
     // loader: rows r0 + 32 i, 16-byte chunk ch (item ch >> 2); tl = fresh_tid()
     auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[8]) {
         const int ch = tl & 15, r0 = tl >> 4, oct = ch & 3;
-        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int bcg = SHARED ? grp % a.NB : grp / gpb, i0 = (SHARED ? grp / a.NB : grp - bcg * gpb) * G;
         const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
         const int item = min(i0 + (ch >> 2), sel3(band, a.nitems[0], a.nitems[1], a.nitems[2]) - 1);
         const h16* sb = sel3(band, a.src[0], a.src[1], a.src[2]) + (long)bcg * sel3(band, a.src_b[0], a.src_b[1], a.src_b[2]) +
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
         fetch(fresh_tid(wave), more ? ngrp : grp, more ? nband : band, pre);  // unconditional (see mf_analysis)
         asm volatile("" ::: "memory");
         const char* img = lds + (it & 1) * IMG_B;
-        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int bcg = SHARED ? grp % a.NB : grp / gpb, i0 = (SHARED ? grp / a.NB : grp - bcg * gpb) * G;
         const int b = bcg / a.CG, cg = bcg - b * a.CG;
         const int hk = lane >> 5;
 
