@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, 
     const int o0 = blockIdx.z * OT;
     const int ty0 = (blockIdx.x / tilesx) * CT, tx0 = (blockIdx.x % tilesx) * CT;
     const int ty = threadIdx.x / CT, tx = threadIdx.x % CT;
-    const int Hs = H >> in.ups, Ws = W >> in.ups;
+    const int Ws = W >> in.ups;
     const T* wb = wts + (long)b * w_bstride;
     float acc[OT];
 #pragma unroll

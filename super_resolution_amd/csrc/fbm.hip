@@ -425,7 +425,7 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
     if (!lists[2].empty()) memcpy(&host[o_c8], lists[2].data(), lists[2].size() * 4);
     memcpy(&host[o_rm], rmask.data(), rmask.size() * 4);
     e = hipMemcpy(dev, host.data(), off, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(dev); free(pl); return hip_fail(e); }
+    if (e != hipSuccess) { (void)hipFree(dev); free(pl); return hip_fail(e); }
     pl->dev_block = dev;
     pl->tw_w = (float2*)(dev + o_tww);
     pl->tw_h = (float2*)(dev + o_twh);
@@ -435,7 +435,7 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
     pl->cols8 = (int*)(dev + o_c8);
     pl->rowmask = (float*)(dev + o_rm);
     const int mrc = fbm_mfma_plan_build(pl, rows.data());
-    if (mrc != SR_OK) { hipFree(dev); free(pl); return mrc; }
+    if (mrc != SR_OK) { (void)hipFree(dev); free(pl); return mrc; }
     *out = pl;
     return SR_OK;
 }

@@ -53,7 +53,6 @@ constexpr int THREADS = 512;
 constexpr int IMG_B = 64 * 1024;  // one staged data image: K rows x G items x 32 channels x fp16
 // Basis tables are stored fragment-major: the 64 x 8 halfs one wave needs for (row tile nt, k-step ks) are 1 KiB
 // contiguous (lane = 32 * (k / 8 % 2) + row % 32).
-constexpr int FRAG = 64 * 8;
 __host__ __device__ inline size_t frag_index(int row, int k, int nks) {
     return ((size_t)((row >> 5) * nks + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
 }

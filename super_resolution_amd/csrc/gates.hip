@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void fbm_gates_kernel(Concat in, int H, int W,
     const int b = blockIdx.y;
     const int ty0 = (blockIdx.x / tilesx) * GT, tx0 = (blockIdx.x % tilesx) * GT;
     const int ty = threadIdx.x / GT, tx = threadIdx.x % GT;
-    const int Hs = H >> in.ups, Ws = W >> in.ups;
+    const int Ws = W >> in.ups;
     const float* wk[3] = {w0, w1, w2};
     float acc[3] = {0.f, 0.f, 0.f};
     for (int s = 0; s < in.nseg; ++s) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
     const unsigned tiles = (unsigned)tilesx * ((H + GMH - 1) / GMH);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hk = lane >> 5;
-    const int Hs = H >> in.ups, Ws = W >> in.ups;
+    const int Ws = W >> in.ups;
     // stage the 27 x cin weight matrix as bf16 (rows 27..31 are zero) -- once per workgroup: the kernel is persistent
     // (staging it per 8 x 32 tile cost more than the tile itself)
     const float* wk[3] = {w0, w1, w2};
