@@ -226,3 +226,86 @@ def test_cpu_tensor_is_refused(sra):
     net = sra.RRDBNet(3, 3, 4, 8, 1, 4)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 8, 8))
+
+
+def test_rrdbnet_fdconv_bf16_psnr_delta_mfma_lowpass(sra):
+    """The same bf16 criterion on 64 x 64 frames, where every trunk tensor takes the MFMA (DFT-as-GEMM) low-pass; the run
+    is repeated on the FFT low-pass kernels and the two bf16 outputs must be equally close to the fp32 oracle."""
+    from super_resolution_amd import _lib
+    sd = t(gp.rrdbnet_state(1, 1, 64, 2, 32, seed=21))
+    net = build_net(sra, (1, 1, 4, 64, 2, 32), sd, True)
+    x = torch.from_numpy(gp.image_input((2, 1, 64, 64), seed=77))
+    ref = rrdbnet_forward(sd, x)
+    target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
+    p_ref = psnr(ref.clamp(0, 1), target)
+    out = {}
+    for name, force_fft in (('mfma', 0), ('fft', 1)):
+        _lib.lib().sr_debug_force_fft_lowpass(force_fft)
+        try:
+            with torch.no_grad():
+                out[name] = net(x.cuda().to(torch.bfloat16)).float().cpu()
+        finally:
+            _lib.lib().sr_debug_force_fft_lowpass(-1)
+        p = psnr(out[name].clamp(0, 1), target)
+        print('%s low-pass: PSNR vs target %.3f dB (fp32 oracle %.3f), direct %.1f dB' % (name, p, p_ref, psnr(out[name], ref)))
+        assert abs(p_ref - p) <= PSNR_DELTA_DB
+    assert psnr(out['mfma'], ref) > psnr(out['fft'], ref) - 1.0
+
+
+def test_full_size_batch_independence_and_shape(sra):
+    """BASELINE.json configs[1] at full size (23 blocks, batch 16 of 512 x 512, bf16): the oracle cannot run this in
+    test time, so the check is a size-independent property of the path -- every statistic of the network is per sample,
+    hence sample i of the batch must come out exactly as when it is run alone (batch / sample offsets, 32-bit index
+    ranges, persistent tile walks at the bench's sizes) -- plus shape, range and finiteness."""
+    sd = t(gp.rrdbnet_state(1, 1, 64, 23, 32, seed=1234))
+    net = build_net(sra, (1, 1, 4, 64, 23, 32), sd, True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(16, 1, 512, 512, generator=g).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        y = net(x)
+        assert y.shape == (16, 1, 2048, 2048) and bool(torch.isfinite(y.float()).all())
+        for i in (0, 11):
+            yi = net(x[i:i + 1].contiguous())
+            d = (yi.float() - y[i:i + 1].float()).abs().max().item()
+            assert d == 0.0, (i, d)
+    assert float(y.float().abs().max()) < 1e3
+
+
+def test_full_size_lowpass_properties(sra):
+    """FBM low-pass planes at the bench's trunk size (16 x 32 ch x 512 x 512, bf16, MFMA path) through properties that
+    need no oracle: linearity, nesting L8(L2(x)) = L8(x) (the bands are nested ideal filters), mean preservation
+    (every band keeps DC) and non-increasing energy x >= L2 >= L4 >= L8."""
+    import ctypes as C
+    from super_resolution_amd import _lib as L
+    lib = L.lib()
+    B, Cc, H, W = 16, 32, 512, 512
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+
+    def lowpass(x):
+        bands = [torch.empty_like(x) for _ in range(3)]
+        pooled = torch.empty(B, Cc, device='cuda:0')
+        L.check(lib.sr_fbm_lowpass(plan, 1, B, L.view(x), 0, L.view(bands[0]), L.view(bands[1]), L.view(bands[2]),
+                                   pooled.data_ptr(), Cc, ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        return [b_.float() for b_ in bands], pooled
+
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(B, H, W, Cc, generator=g) - 0.3).to(torch.bfloat16).cuda()  # NHWC, 32 channels
+    y = (torch.rand(B, H, W, Cc, generator=g) - 0.5).to(torch.bfloat16).cuda()
+    Lx, px = lowpass(x)
+    Ly, _ = lowpass(y)
+    z = (x.float() * 0.5 + y.float()).to(torch.bfloat16)
+    Lz, _ = lowpass(z)
+    tol = 3 * 2.0 ** -8  # a few bf16 roundings of O(1) values
+    for k in range(3):
+        assert (Lz[k] - (0.5 * Lx[k] + Ly[k])).abs().max().item() < tol, k
+        assert (Lx[k].mean(dim=(1, 2)) - x.float().mean(dim=(1, 2))).abs().max().item() < 1e-3, k
+    assert (px - x.float().mean(dim=(1, 2))).abs().max().item() < 2e-4
+    L8_of_L2, _ = lowpass(Lx[0].to(torch.bfloat16))
+    assert (L8_of_L2[2] - Lx[2]).abs().max().item() < tol
+    e = [float(x.float().pow(2).sum())] + [float(v.pow(2).sum()) for v in Lx]
+    assert e[0] >= e[1] * (1 - 1e-3) and e[1] >= e[2] * (1 - 1e-3) and e[2] >= e[3] * (1 - 1e-3), e
+    lib.sr_fbm_plan_destroy(plan)
