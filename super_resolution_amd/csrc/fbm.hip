@@ -87,39 +87,57 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 
 // One autosort pass of radix R over `src` (N points x P signals, signal index innermost).
-// Each work item produces one output point of one signal.  `premul`, when set, scales source
-// point i by premul[i] (the row mask, applied while reading the spectrum).
-template <bool INV>
-__device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
-                                         int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+// Each work item produces one output point of PP consecutive signals (index arithmetic and the twiddle of every
+// butterfly term are shared by them).  `premul`, when set, scales source point i by premul[i] (the row mask,
+// applied while reading the spectrum).
+template <bool INV, int PP>
+__device__ __forceinline__ void fft_pass_pp(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
+                                            int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
     const int NR = N / R;
     const int tstep = N / (Ns * R);
-    for (int it = threadIdx.x; it < N * P; it += blockDim.x) {
-        const int p = it % P;
-        const int o = it / P;
+    const int PG = P / PP;
+    for (int it = threadIdx.x; it < N * PG; it += blockDim.x) {
+        const int pg = it % PG;
+        const int o = it / PG;
         const int k = o % Ns;
         const int u = (o / Ns) % R;
         const int j = (o / (Ns * R)) * Ns + k;
         const int q = k * tstep + u * NR;  // < N
-        float2 acc = make_float2(0.f, 0.f);
+        float2 acc[PP];
+#pragma unroll
+        for (int i = 0; i < PP; ++i) acc[i] = make_float2(0.f, 0.f);
         int tq = 0;
         for (int t = 0; t < R; ++t) {
             float2 w = tw[tq];
             if (INV) w.y = -w.y;
             const int si = j + t * NR;
-            float2 v = src[si * P + p];
             if (premul) {
                 const float m = premul[si];
-                v.x *= m;
-                v.y *= m;
+                w.x *= m;
+                w.y *= m;
             }
-            acc.x += v.x * w.x - v.y * w.y;
-            acc.y += v.x * w.y + v.y * w.x;
+            const float2* sp = src + si * P + pg * PP;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const float2 v = sp[i];
+                acc[i].x += v.x * w.x - v.y * w.y;
+                acc[i].y += v.x * w.y + v.y * w.x;
+            }
             tq += q;
             if (tq >= N) tq -= N;
         }
-        dst[o * P + p] = acc;
+        float2* dp = dst + o * P + pg * PP;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) dp[i] = acc[i];
     }
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
+                                         int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+    if ((P & 3) == 0) fft_pass_pp<INV, 4>(src, dst, N, R, Ns, P, tw, premul);
+    else if ((P & 1) == 0) fft_pass_pp<INV, 2>(src, dst, N, R, Ns, P, tw, premul);
+    else fft_pass_pp<INV, 1>(src, dst, N, R, Ns, P, tw, premul);
 }
 
 // Runs all passes; returns the buffer that holds the result.  bufA holds the input.  When
@@ -150,10 +168,11 @@ __global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int 
                                                     float2* __restrict__ t1) {
     float2* bufA = (float2*)smem;
     float2* bufB = bufA + W * P;
+    float2* twl = bufB + W * P;  // twiddles staged in LDS: every butterfly term reads one
+    for (int i = threadIdx.x; i < W; i += blockDim.x) twl[i] = tw[i];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int p0 = blockIdx.y * P;
-    const int Hs = H >> ups, Ws = W >> ups;
-    (void)Hs;
+    const int Ws = W >> ups;
     for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
         const int p = it % P, w = it / P;
         const int c = 2 * (p0 + p);
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int 
         bufA[it] = v;
     }
     __syncthreads();
-    const float2* res = fft_run<false>(bufA, bufB, nullptr, false, W, rx, P, tw, nullptr);
+    const float2* res = fft_run<false>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
     // t1[b][idx][h][PT]
     for (int it = threadIdx.x; it < n2 * P; it += blockDim.x) {
         const int p = it % P, idx = it / P;
@@ -182,6 +201,8 @@ __global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Rad
     float2* buf0 = (float2*)smem;
     float2* buf1 = buf0 + H * P;
     float2* buf2 = buf1 + H * P;
+    float2* twl = buf2 + H * P;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) twl[i] = tw[i];
     const int b = blockIdx.x / n2, idx = blockIdx.x % n2;
     const int p0 = blockIdx.y * P;
     const float2* col = t1 + ((long)b * n2 + idx) * H * PT;
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Rad
         buf0[it] = (p0 + p < PT) ? col[(long)h * PT + p0 + p] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    float2* S = fft_run<false>(buf0, buf1, nullptr, false, H, rx, P, tw, nullptr);
+    float2* S = fft_run<false>(buf0, buf1, nullptr, false, H, rx, P, twl, nullptr);
     float2* other = (S == buf0) ? buf1 : buf0;
     const int variant = colinfo[idx * 4 + 0];
     if (pooled && idx == 0 && threadIdx.x < P) {  // column 0 comes first: S[0] = plane sums of the pair
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Rad
     for (int k = 0; k < 3; ++k) {
         if (kidx[k] < 0) continue;  // block-uniform
         const float* rm = rowmask + (k * 3 + variant) * H;
-        const float2* res = fft_run<true>(S, buf2, other, true, H, rx, P, tw, rm);
+        const float2* res = fft_run<true>(S, buf2, other, true, H, rx, P, twl, rm);
         float2* y = ys[k];
         for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
             const int p = it % P, h = it / P;
@@ -225,6 +246,8 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
                                                     const float2* __restrict__ y8) {
     float2* bufA = (float2*)smem;
     float2* bufB = bufA + W * P;
+    float2* twl = bufB + W * P;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) twl[i] = tw[i];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int p0 = blockIdx.y * P;
     const float norm = 1.0f / ((float)H * (float)W);
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
             if (p0 + p < PT) bufA[ck[k][i] * P + p] = yr[(long)i * PT + p0 + p];
         }
         __syncthreads();
-        const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, tw, nullptr);
+        const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
             const int p = it % P, w = it / P;
             const int c = 2 * (p0 + p);
@@ -290,7 +313,7 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     float2* y8 = y4 + (size_t)B * H * n4 * PT;
     const Radix rw = make_radix(pl->radW, pl->nfW), rh = make_radix(pl->radH, pl->nfH);
     const int Pw = pl->Pw, Ph = pl->Ph;
-    const size_t lds_w = 2ul * W * Pw * sizeof(float2), lds_h = 3ul * H * Ph * sizeof(float2);
+    const size_t lds_w = (2ul * W * Pw + W) * sizeof(float2), lds_h = (3ul * H * Ph + H) * sizeof(float2);  // buffers + twiddles
     dim3 g1(B * H, cdiv(PT, Pw)), g2(B * n2, cdiv(PT, Ph));
     if (dtype == SR_F32) {
         SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
