@@ -345,6 +345,8 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 using namespace sr;
 
 extern "C" void sr_debug_force_generic_fft(int on) { sr::g_force_generic_fft = on; }
+namespace sr { extern int g_mfma_no_fold; }
+extern "C" void sr_debug_mfma_no_fold(int on) { sr::g_mfma_no_fold = on; }
 extern "C" void sr_debug_force_fft_lowpass(int on) { sr::g_force_fft_lowpass = on < 0 ? sr::lowpass_default() : on; }
 
 extern "C" int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host) {

@@ -494,6 +494,147 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// synthesis along W, folded (W a multiple of 64): the cos functions are even and the sin functions odd about w = 0, so
+//     L[w] = E[w] + O[w],   L[W - w] = E[w] - O[w]      (E = sum over the cos coefficients, O = over the sin ones)
+// for w = 0 .. W/2 - 1: two products of half the depth for half the columns -- half the MFMA work of mf_synthesis<false>
+// and half the basis registers.  The staged image holds the cos coefficients (even j) in rows 0..127 and the sin
+// coefficients in rows 128..255.  The column w = W/2 (where every sin vanishes) is one more basis tile, run by wave 0.
+// Basis table: tiles 0 .. W/64 - 1 = columns w (k-steps 0..7 cos, 8..15 sin), tile W/64 = column W/2 in its row 0.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
+    constexpr int G = 4, ROWB = 256, KH = 8, SIN0 = 128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTh = a.M >> 6;  // column tiles of the first half
+    const int tw = min(wave, NTh - 1);
+    half8 bE[KH], bO[KH], bN[KH];
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+        bE[ks] = *(const half8*)(a.basis + ((size_t)(tw * 16 + ks) * 64 + lane) * 8);
+        bO[ks] = *(const half8*)(a.basis + ((size_t)(tw * 16 + KH + ks) * 64 + lane) * 8);
+        bN[ks] = *(const half8*)(a.basis + ((size_t)(NTh * 16 + ks) * 64 + lane) * 8);
+    }
+    const int gpb = (a.nitems[0] + G - 1) / G, ngroups = a.NB * gpb;
+    auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[8]) {
+        const int ch = tl & 15, r0 = tl >> 4, oct = ch & 3;
+        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
+        const int item = min(i0 + (ch >> 2), sel3(band, a.nitems[0], a.nitems[1], a.nitems[2]) - 1);
+        const h16* sb = sel3(band, a.src[0], a.src[1], a.src[2]) + (long)bcg * sel3(band, a.src_b[0], a.src_b[1], a.src_b[2]) +
+                        (long)item * sel3(band, a.src_i[0], a.src_i[1], a.src_i[2]) + oct * 8;
+        const int sk = sel3(band, a.src_k[0], a.src_k[1], a.src_k[2]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 32 * i, K - 1) * sk);
+    };
+    // coefficient j = r0 + 32 i -> image row (j >> 1) + 128 (j & 1); all 256 rows are written (zeros from j = K on)
+    auto stash = [&](int tl, const uint4 (&pre)[8], char* img, int band) {
+        const int ch = tl & 15, r0 = tl >> 4;
+        const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (r0 >> 1) + 16 * i + (r0 & 1) * SIN0;
+            *(uint4*)(img + img_off<G>(row, ch)) = r0 + 32 * i < K ? pre[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    int grp = blockIdx.x, band = 0;
+    if (grp >= ngroups) return;
+    uint4 pre[8];
+    fetch(tid, grp, 0, pre);
+    stash(tid, pre, lds, 0);
+    __syncthreads();
+    for (unsigned it = 0;; ++it) {
+        int ngrp = grp, nband = band + 1;
+        if (nband == 3) {
+            nband = 0;
+            ngrp = grp + gridDim.x;
+        }
+        const bool more = ngrp < ngroups;
+        fetch(fresh_tid(wave), more ? ngrp : grp, more ? nband : band, pre);  // unconditional (see mf_analysis)
+        asm volatile("" ::: "memory");
+        const char* img = lds + (it & 1) * IMG_B;
+        const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
+        const int b = bcg / a.CG, cg = bcg - b * a.CG;
+        const int hk = lane >> 5;
+        const int nit = sel3(band, a.nitems[0], a.nitems[1], a.nitems[2]);
+        const int kend = sel3(band, a.ksm[0], a.ksm[1], a.ksm[2]);  // k-steps per half
+        const View o = sel3(band, a.out[0], a.out[1], a.out[2]);
+        bf16_t* ob = (bf16_t*)o.p + (long)b * o.bs;
+        const int m = tw * 32 + (lane & 31);
+        auto store = [&](int g, int col, const uint4& lo, const uint4& hi) {
+            uint4* d = (uint4*)(ob + voff32(o, (unsigned)min(i0 + g, nit - 1) * a.Wout + col, cg * 32 + hk * 16));
+            d[0] = lo;
+            d[1] = hi;
+        };
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto nyquist = [&](int g) {  // wave 0: the column W / 2 of item g
+            const int ta0 = tr_addr<G>(lane, g, 0), ta1 = tr_addr<G>(lane, g, 1);
+            f32x16 accN;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) {
+                if (ks && ks >= kend) break;
+                accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_read(img + ks * 16 * ROWB, ta0, ta1), bN[ks], ks ? accN : z, 0, 0, 0);
+            }
+            uint4 lo, hi;
+            tile_to_rows<true>(accN, 1.0f, lo, hi);
+            if ((lane & 31) == 0) store(g, a.Wout >> 1, lo, hi);
+        };
+        uint4 held[2][2][2];  // packed sum / difference rows of items 0 and 1, kept until the next image has been staged
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int ta0 = tr_addr<G>(lane, g, 0), ta1 = tr_addr<G>(lane, g, 1);
+            f32x16 accE, accO;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) {
+                if (ks && ks >= kend) break;
+                const half8 dE = tr_read(img + ks * 16 * ROWB, ta0, ta1);
+                const half8 dO = tr_read(img + (SIN0 + ks * 16) * ROWB, ta0, ta1);
+                accE = __builtin_amdgcn_mfma_f32_32x32x16_f16(dE, bE[ks], ks ? accE : z, 0, 0, 0);
+                accO = __builtin_amdgcn_mfma_f32_32x32x16_f16(dO, bO[ks], ks ? accO : z, 0, 0, 0);
+            }
+            f32x16 sum, dif;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sum[i] = accE[i] + accO[i];
+                dif[i] = accE[i] - accO[i];
+            }
+            uint4 slo, shi, dlo, dhi;
+            tile_to_rows<true>(sum, 1.0f, slo, shi);
+            tile_to_rows<true>(dif, 1.0f, dlo, dhi);
+            if (g < 2) {
+                held[g][0][0] = slo;
+                held[g][0][1] = shi;
+                held[g][1][0] = dlo;
+                held[g][1][1] = dhi;
+            } else {
+                store(g, m, slo, shi);
+                if (m > 0) store(g, a.Wout - m, dlo, dhi);
+                if (wave == 0) nyquist(g);
+            }
+            if (g == 1) {
+                // stage the next image before the first store of this group goes out (see mf_analysis)
+                if (more) stash(fresh_tid(wave), pre, lds + ((it + 1) & 1) * IMG_B, nband);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    store(gg, m, held[gg][0][0], held[gg][0][1]);
+                    if (m > 0) store(gg, a.Wout - m, held[gg][1][0], held[gg][1][1]);
+                }
+                if (wave == 0) {
+                    nyquist(0);
+                    nyquist(1);
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();
+        grp = ngrp;
+        band = nband;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host: tables, eligibility, launch
 // ---------------------------------------------------------------------------------------------------------------
 static int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -573,12 +714,14 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     }
     pl->mf_ld_qw = pad_to(jw, 32);
     pl->mf_ld_ph = pad_to(nh, 32);
+    const bool fold = W % 64 == 0 && jw <= 256;  // folded synthesis along W (mf_synthesis_wf)
+    const size_t n_qwf = fold ? (size_t)(W / 64 + 1) * 16 * 64 * 8 : 0;
     const size_t n_qwt = (size_t)pad_to(jw, 32) * W, n_qw = (size_t)pad_to(W, 32) * pl->mf_ld_qw, n_pht = (size_t)pad_to(nh, 32) * H,
                  n_ph = (size_t)pad_to(H, 32) * pl->mf_ld_ph;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_qwt = carve(n_qwt * sizeof(h16)), o_qw = carve(n_qw * sizeof(h16)), o_pht = carve(n_pht * sizeof(h16)),
-                 o_ph = carve(n_ph * sizeof(h16)), o_win = carve(win.size() * sizeof(float));
+                 o_ph = carve(n_ph * sizeof(h16)), o_win = carve(win.size() * sizeof(float)), o_qwf = carve(n_qwf * sizeof(h16));
     std::vector<char> host(off, 0);
     h16* qwt = (h16*)&host[o_qwt];
     h16* qw = (h16*)&host[o_qw];
@@ -597,6 +740,15 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
             ph[frag_index(h, n, pl->mf_ld_ph / 16)] = (h16)(16.0 * v);  // S is kept as S / 16 in fp16
         }
     memcpy(&host[o_win], win.data(), win.size() * sizeof(float));
+    if (fold) {
+        h16* qwf = (h16*)&host[o_qwf];
+        for (int w = 0; w < W / 2; ++w)
+            for (int c = 0; c < jw / 2; ++c) {  // k = c: cos coefficient 2c; k = 128 + c: sin coefficient 2c + 1
+                qwf[frag_index(w, c, 16)] = (h16)basis_val(2 * c, w, W);
+                qwf[frag_index(w, 128 + c, 16)] = (h16)basis_val(2 * c + 1, w, W);
+            }
+        for (int c = 0; c < jw / 2; ++c) qwf[frag_index(W / 2, c, 16)] = (h16)basis_val(2 * c, W / 2, W);
+    }
     char* dev = nullptr;
     SR_HIP(hipMalloc((void**)&dev, off));
     const hipError_t e = hipMemcpy(dev, host.data(), off, hipMemcpyHostToDevice);
@@ -610,6 +762,7 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     pl->mf_pht = dev + o_pht;
     pl->mf_ph = dev + o_ph;
     pl->mf_win = dev + o_win;
+    pl->mf_qwf = fold ? dev + o_qwf : nullptr;
     pl->mf_ok = 1;
     return SR_OK;
 }
@@ -622,6 +775,7 @@ static bool view32_ok(const View& v, int C) {
 }
 
 int g_mfma_cus = 0;
+int g_mfma_no_fold = 0;  // debug hook: W-synthesis without the even / odd fold
 
 int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
                      int pooled_ld, void* ws, hipStream_t st) {
@@ -729,10 +883,18 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     s4.M = W;
     s4.NB = NB;
     s4.CG = CG;
-    s4.basis = (const h16*)pl->mf_qw;
-    s4.nks_tab = pl->mf_ld_qw / 16;
-    SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_syn));
-    mf_synthesis<false><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
+    if (pl->mf_qwf && !g_mfma_no_fold) {
+        for (int k = 0; k < 3; ++k) s4.ksm[k] = (pl->mf_nw[k] / 2 + 15) / 16;  // k-steps per half (cos / sin)
+        s4.basis = (const h16*)pl->mf_qwf;
+        s4.nks_tab = 16;
+        SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis_wf, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_B));
+        mf_synthesis_wf<<<grid_for(H, 4), THREADS, 2 * IMG_B, st>>>(s4);
+    } else {
+        s4.basis = (const h16*)pl->mf_qw;
+        s4.nks_tab = pl->mf_ld_qw / 16;
+        SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_syn));
+        mf_synthesis<false><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
+    }
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

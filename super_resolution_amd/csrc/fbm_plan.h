@@ -31,6 +31,7 @@ struct sr_fbm_plan {
     void* mf_qw;           // fp16 [pad32(W)][pad16(jw)] q_j[w]      synthesis along W (band k uses the first nw[k] functions)
     void* mf_pht;          // fp16 [pad32(nh)][H]      p_n[h]        analysis along H
     void* mf_ph;           // fp16 [pad32(H)][pad16(nh)] 16 p_n[h]   synthesis along H (shared by the three bands)
+    void* mf_qwf;          // fp16 folded synthesis along W (W % 64 == 0): tiles of columns 0 .. W/2 - 1, k = cos | sin halves; last tile = column W/2
     void* mf_win;          // float2 [3][32]: (s, d) weights of the 32 y-coefficient rows after the main k-steps of band k
     int mf_ksm[3];         // main k-steps of band k: y-coefficients 0 .. 16 * ksm - 1 enter with weight one
     int mf_nwin[3];        // window k-steps after them (0..2)
