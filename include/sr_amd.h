@@ -151,7 +151,7 @@ int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in, const sr_l
 typedef struct {
     const float* w[3]; /* gate weights of this consumer at the segment's first channel: [C][3*3] per k */
     const float* b[3]; /* gate biases (used when first != 0) */
-    float* logits;     /* (B,H,W,4) float accumulator of this consumer; read unless first, written unless gates != NULL */
+    float* logits;     /* (B,H,W,3) float accumulator of this consumer; read unless first, written unless gates != NULL */
     float* gates;      /* non-NULL: seg is this consumer's last segment -> write 2*sigmoid(logits) here (B,H,W,4) */
     int32_t first;     /* non-zero: seg is this consumer's first segment (start from the bias) */
 } sr_gate_consumer;

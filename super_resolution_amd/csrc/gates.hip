@@ -202,6 +202,11 @@ __global__ __launch_bounds__(256) void fbm_gates_mfma(Concat in, int B, int H, i
 // 27 x C weight slice); per consumer the T image goes through the same LDS buffer and the 9-tap sum is added to the
 // consumer's logits (or finished as 2*sigmoid into the gates buffer).
 // ---------------------------------------------------------------------------------------------
+// running logits of one consumer: three floats per pixel, packed (12-byte loads and stores)
+struct Logit3 {
+    float x, y, z;
+};
+
 template <int NC>
 __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H, int W, GateConsList cl) {
     extern __shared__ __attribute__((aligned(16))) char glds[];
@@ -257,13 +262,13 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
         // running logits of every consumer, fetched together with the fragments (unconditional, clamped: a load behind
         // a branch, or issued after the previous consumer's store, waits for the memory pipe to drain)
         const long pix = ((long)b * H + min(h, H - 1)) * W + min(w, W - 1);
-        float4 lgp[NC];
+        Logit3 lgp[NC];
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
-            // a consumer that starts from its bias reads (and ignores) 16 bytes of the segment itself: cached, always valid
+            // a consumer that starts from its bias reads (and ignores) 12 bytes of the segment itself: cached, always valid
             const char* src = cl.c[ci].first ? (const char*)((const bf16_t*)seg.p + voff(seg, b, pix - (long)b * H * W, 0))
-                                             : (const char*)(cl.c[ci].logits + 4 * pix);
-            lgp[ci] = *(const float4*)src;
+                                             : (const char*)(cl.c[ci].logits + 3 * pix);
+            lgp[ci] = *(const Logit3*)src;
         }
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
@@ -309,8 +314,7 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
                     g.w = 0.f;
                     ((float4*)gc.gates)[pix] = g;
                 } else {
-                    g = make_float4(lg[0], lg[1], lg[2], 0.f);
-                    ((float4*)gc.logits)[pix] = g;
+                    ((Logit3*)gc.logits)[pix] = Logit3{lg[0], lg[1], lg[2]};
                 }
             }
         }

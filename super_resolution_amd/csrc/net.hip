@@ -94,7 +94,7 @@ Layout make_layout(const sr_rrdbnet* net, int dtype, int B, int H, int W) {
         L.band_u1 = carve(3 * n2 * net->nf * es);
         L.band_hr = carve(3 * n4 * net->nf * es);
         L.gates = carve(n4 * 4 * sizeof(float));
-        for (int i = 0; i < 5; ++i) L.logit[i] = carve(n1 * 4 * sizeof(float));  // dense-block gate accumulators
+        for (int i = 0; i < 5; ++i) L.logit[i] = carve(n1 * 3 * sizeof(float));  // dense-block gate accumulators
         const int cmax = net->nf + 4 * net->gc;
         L.pooled = carve((size_t)B * cmax * sizeof(float));
         L.wdyn = carve((size_t)B * 9 * net->nf * cmax * es);

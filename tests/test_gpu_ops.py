@@ -417,7 +417,7 @@ def test_fbm_gates_accumulate_dense_block(L, cb):
     cins = [64, 96, 128, 160, 192]
     gw = [[dev(rnd((cin, 9), 400 + 10 * j + k, 0.05)).contiguous() for k in range(3)] for j, cin in enumerate(cins)]
     gb = [[dev(rnd((1,), 500 + 10 * j + k)).contiguous() for k in range(3)] for j in range(5)]
-    logits = [torch.full((B, H, W, 4), float('nan'), device='cuda:0') for _ in range(5)]
+    logits = [torch.full((B, H, W, 3), float("nan"), device="cuda:0") for _ in range(5)]
     gates = [torch.full((B, H, W, 4), float('nan'), device='cuda:0') for _ in range(5)]
     c0 = 0
     for s_ in range(5):  # segment s_ feeds consumers s_ .. 4; it is the last input of consumer s_
