@@ -294,6 +294,12 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
 // synthesis: out[item][m] = sum_k data[item][k] basis[m][k];  K <= 256, M <= 512: two 32-function basis tiles per
 // wave, four items per staged image (K rows x 256 bytes), three bands per item group
 // ---------------------------------------------------------------------------------------------------------------
+// U_k (the coefficient rows between the two synthesis passes) is stored by groups of four coefficient columns,
+// U_k[bcg][j / 4][h][j % 4][32]: the H-synthesis writes, for its four columns, 256 contiguous bytes per row h and whole
+// kilobytes per wave (column-major rows of 64 bytes were half-line writes 16 KiB apart); the W-synthesis reads 1 KiB runs.
+// `base` already points at (bcg, row h, channel octet); k = coefficient column.
+__device__ __forceinline__ const h16* u_addr(const h16* base, int k, int H) { return base + ((long)(k >> 2) * H) * 128 + (k & 3) * 32; }
+
 constexpr int WIN_ROWS = 32;                   // window rows per band (two k-steps)
 constexpr int WIN_B = 3 * WIN_ROWS * 256;      // 24 KiB
 struct SynArgs {
@@ -351,7 +357,10 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                         (long)item * sel3(band, a.src_i[0], a.src_i[1], a.src_i[2]) + oct * 8;
         const int sk = sel3(band, a.src_k[0], a.src_k[1], a.src_k[2]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 32 * i, K - 1) * sk);
+        for (int i = 0; i < 8; ++i) {
+            const int k = min(r0 + 32 * i, K - 1);
+            pre[i] = *(const uint4*)(SHARED ? sb + (long)k * sk : u_addr(sb, k, a.nitems[0]));
+        }
     };
     // all 256 rows are written (zeros from row K on): the k loop always runs its 16 steps -- a branch per k-step costs a
     // copy of the accumulators at every join -- and the basis registers are shared by bands of different K
@@ -431,8 +440,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                     uint4* d;
                     if (SHARED) {
                         d = (uint4*)(sel3(k, a.dst[0], a.dst[1], a.dst[2]) + (long)bcg * sel3(k, a.dst_b[0], a.dst_b[1], a.dst_b[2]) +
-                                     (long)m * sel3(k, a.dst_m[0], a.dst_m[1], a.dst_m[2]) +
-                                     (long)ig * sel3(k, a.dst_i[0], a.dst_i[1], a.dst_i[2]) + hk * 16);
+                                     ((long)(ig >> 2) * a.M + m) * 128 + (ig & 3) * 32 + hk * 16);
                     } else {
                         const View o = sel3(k, a.out[0], a.out[1], a.out[2]);
                         d = (uint4*)((bf16_t*)o.p + (long)b * o.bs + voff32(o, (unsigned)ig * a.Wout + m, cg * 32 + hk * 16));
@@ -524,8 +532,9 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
         const h16* sb = sel3(band, a.src[0], a.src[1], a.src[2]) + (long)bcg * sel3(band, a.src_b[0], a.src_b[1], a.src_b[2]) +
                         (long)item * sel3(band, a.src_i[0], a.src_i[1], a.src_i[2]) + oct * 8;
         const int sk = sel3(band, a.src_k[0], a.src_k[1], a.src_k[2]);
+        (void)sk;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 32 * i, K - 1) * sk);
+        for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)u_addr(sb, min(r0 + 32 * i, K - 1), a.nitems[0]);
     };
     // coefficient j = r0 + 32 i -> image row (j >> 1) + 128 (j & 1); all 256 rows are written (zeros from j = K on)
     auto stash = [&](int tl, const uint4 (&pre)[8], char* img, int band) {
@@ -792,11 +801,13 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     const int jw = pl->mf_jw, nh = pl->mf_nh;
     h16* T = (h16*)ws;                      // [NB][H][jw][32]
     h16* S = T + (size_t)NB * H * jw * 32;  // [NB][nh][jw][32]
-    h16* U[3];                              // [NB][H][nw[k]][32]
+    h16* U[3];                              // [NB][nw[k] / 4][H][4][32]
+    size_t usz[3];  // halfs per bcg: column groups of four, padded
+    for (int k = 0; k < 3; ++k) usz[k] = (size_t)((pl->mf_nw[k] + 3) / 4) * H * 128;
     U[0] = S + (size_t)NB * nh * jw * 32;
-    U[1] = U[0] + (size_t)NB * H * pl->mf_nw[0] * 32;
-    U[2] = U[1] + (size_t)NB * H * pl->mf_nw[1] * 32;
-    if ((size_t)((char*)(U[2] + (size_t)NB * H * pl->mf_nw[2] * 32) - (char*)ws) > sr_fbm_workspace_bytes(pl, B, C)) return SR_NOT_ELIGIBLE;
+    U[1] = U[0] + (size_t)NB * usz[0];
+    U[2] = U[1] + (size_t)NB * usz[1];
+    if ((size_t)((char*)(U[2] + (size_t)NB * usz[2]) - (char*)ws) > sr_fbm_workspace_bytes(pl, B, C)) return SR_NOT_ELIGIBLE;
     auto grid_for = [&](long items, int G) { return (int)std::min<long>((long)NB * ((items + G - 1) / G), g_mfma_cus); };
     const int lds_ana = 2 * IMG_B, lds_syn = 2 * IMG_B + WIN_B + 3 * WIN_ROWS * (int)sizeof(float2);
 
@@ -852,8 +863,8 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s3.ksm[k] = pl->mf_ksm[k];
         s3.nwin[k] = pl->mf_nwin[k];
         s3.dst[k] = U[k];
-        s3.dst_b[k] = (long)H * pl->mf_nw[k] * 32;
-        s3.dst_m[k] = pl->mf_nw[k] * 32;
+        s3.dst_b[k] = (long)usz[k];  // grouped layout, see u_addr
+        s3.dst_m[k] = 128;
         s3.dst_i[k] = 32;
         s3.nitems[k] = pl->mf_nw[k];
     }
@@ -871,9 +882,9 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     const View outs[3] = {l2, l4, l8};
     for (int k = 0; k < 3; ++k) {
         s4.src[k] = U[k];
-        s4.src_b[k] = (long)H * pl->mf_nw[k] * 32;
+        s4.src_b[k] = (long)usz[k];  // grouped layout: row h at + h * 128, column k through u_addr
         s4.src_k[k] = 32;
-        s4.src_i[k] = pl->mf_nw[k] * 32;
+        s4.src_i[k] = 128;
         s4.K[k] = pl->mf_nw[k];
         s4.ksm[k] = (pl->mf_nw[k] + 15) / 16;
         s4.out[k] = outs[k];
