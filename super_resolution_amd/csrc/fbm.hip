@@ -347,6 +347,8 @@ using namespace sr;
 extern "C" void sr_debug_force_generic_fft(int on) { sr::g_force_generic_fft = on; }
 namespace sr { extern int g_mfma_no_fold; }
 extern "C" void sr_debug_mfma_no_fold(int on) { sr::g_mfma_no_fold = on; }
+namespace sr { namespace fast { extern int g_no_ups_shortcut; } }
+extern "C" void sr_debug_no_ups_shortcut(int on) { sr::fast::g_no_ups_shortcut = on; }
 extern "C" void sr_debug_force_fft_lowpass(int on) { sr::g_force_fft_lowpass = on < 0 ? sr::lowpass_default() : on; }
 
 extern "C" int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host) {

@@ -278,6 +278,49 @@ __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int 
     fft<N, P, false, BLK, 1, false, 0, fwd_oz<N, PZ>()>(buf, twl, lf, sl);
 }
 
+// ---- rows forward of a nearest-2x upsampled tensor -----------------------------------------------
+// The source row s (N = W / 2 pixels) appears as rows 2h, 2h + 1 of the upsampled image, every pixel twice:
+//     FFT_W(up(s))[k] = (1 + w^k) FFT_N(s)[k mod N],   w = exp(-2 pi i / W),
+// so one N-point transform per SOURCE row serves two rows of T1 (a quarter of the butterflies of rows_fwd on the
+// upsampled rows).  tw = twiddles of length W (every second one is the N-point table).
+template <typename T, int N, int P, bool BLK>
+__global__ __launch_bounds__(THREADS) void rows_fwd_up(View x, int H, int PT, Inter im, const float2* __restrict__ tw, int a2,
+                                                       float2* __restrict__ t1) {
+    constexpr int W = 2 * N;
+    float2* buf = (float2*)smem_fast;
+    float2* twl = buf + N * P;
+    for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = tw[2 * i];
+    __syncthreads();
+    unsigned bx, by;
+    block_xy(im, bx, by);
+    const int Hs = H >> 1;
+    const int b = bx / Hs, hs = bx % Hs;
+    const int p0 = by * P;
+    const int n2 = 2 * a2 - 1;
+    const unsigned rowpix = (unsigned)hs * N;
+    const T* xb = (const T*)x.p + (long)b * x.bs;
+    float2* t1b = t1 + ((long)b * im.NPG * n2 * H << im.QL);
+    auto lf = [&](int idx, int p, int, int) {
+        return (p0 + p < PT) ? Pair<T>::ld(xb + voff32(x, rowpix + idx, 2 * (p0 + p))) : make_float2(0.f, 0.f);
+    };
+    auto sl = [&](int idx, int p, float2 v) {
+        if (p0 + p >= PT) return;
+        const float2 w = tw[idx];  // w^idx; w^(idx + N) = -w^idx
+        if (idx < a2) {
+            const float2 o = make_float2(v.x + v.x * w.x - v.y * w.y, v.y + v.x * w.y + v.y * w.x);
+            t1b[t1_off(im, p0 + p, idx, 2 * hs, n2, H)] = o;
+            t1b[t1_off(im, p0 + p, idx, 2 * hs + 1, n2, H)] = o;
+        }
+        if (idx > N - a2) {
+            const float2 o = make_float2(v.x - (v.x * w.x - v.y * w.y), v.y - (v.x * w.y + v.y * w.x));
+            const int pos = kept_pos<W>(idx + N, a2);
+            t1b[t1_off(im, p0 + p, pos, 2 * hs, n2, H)] = o;
+            t1b[t1_off(im, p0 + p, pos, 2 * hs + 1, n2, H)] = o;
+        }
+    };
+    fft<N, P, false, BLK, 1, false, 0, 0>(buf, twl, lf, sl);
+}
+
 // ---- columns: forward, mask, inverse x3 ------------------------------------------------------
 template <int N, int P, bool BLK, bool PZ>
 __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
@@ -422,9 +465,21 @@ __global__ __launch_bounds__(THREADS, 4) void rows_inv(View l2, View l4, View l8
 constexpr int pairs_for(int n) { return n <= 512 ? 16 : (n == 1024 ? 8 : 4); }
 inline int pairs_for_rt(int n) { return pairs_for(n); }
 
+int g_no_ups_shortcut = 0;  // debug hook
+
 template <typename T, int N, bool BLK>
 static int launch_rows_fwd(View x, int ups, int B, int H, int PT, Inter im, const sr_fbm_plan* pl, float2* t1,
                            hipStream_t st) {
+    if constexpr (N >= 128) {
+        if (ups == 1 && pl->half[0] <= N / 2 && !g_no_ups_shortcut) {  // one half-length transform per source row
+            constexpr int NS = N / 2, PS = pairs_for(NS);
+            const size_t ldss = (size_t)NS * PS * sizeof(float2) + (size_t)NS * sizeof(float2);
+            SR_HIP(hipFuncSetAttribute((const void*)rows_fwd_up<T, NS, PS, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
+            rows_fwd_up<T, NS, PS, BLK><<<dim3(B * (H / 2), cdiv(PT, PS)), THREADS, ldss, st>>>(x, H, PT, im, pl->tw_w, pl->half[0], t1);
+            SR_LAUNCH_CHECK();
+            return SR_OK;
+        }
+    }
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
     // kept columns of the widest mask inside the outer quarters: the last pass skips the middle half of its outputs

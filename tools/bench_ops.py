@@ -29,25 +29,26 @@ def timeit(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0, force_fft=1):
+def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0, force_fft=1, ups=0):
     lib.sr_debug_force_fft_lowpass(force_fft)
     plan = C.c_void_p()
     L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
     shape = (B, Cc // blocked, H, W, blocked) if blocked else (B, H, W, Cc)
+    xshape = (B, Cc // blocked, H >> ups, W >> ups, blocked) if blocked else (B, H >> ups, W >> ups, Cc)
     mk = L.blocked_view if blocked else L.view
-    x = torch.rand(shape, device=dev).to(torch.bfloat16)
-    bands = [torch.empty_like(x) for _ in range(3)]
+    x = torch.rand(xshape, device=dev).to(torch.bfloat16)
+    bands = [torch.empty(shape, device=dev, dtype=torch.bfloat16) for _ in range(3)]
     pooled = torch.empty(B, Cc, device=dev)
     ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device=dev)
 
     def run():
-        L.check(lib.sr_fbm_lowpass(plan, 1, B, mk(x), 0, mk(bands[0]), mk(bands[1]), mk(bands[2]), pooled.data_ptr(), Cc,
+        L.check(lib.sr_fbm_lowpass(plan, 1, B, mk(x), ups, mk(bands[0]), mk(bands[1]), mk(bands[2]), pooled.data_ptr(), Cc,
                                    ws.data_ptr(), ws.numel(), st))
     t = timeit(run, reps)
     px = B * H * W * Cc
     lib.sr_debug_force_fft_lowpass(-1)
-    print('lowpass C=%d %dx%d B=%d blocked=%d fft=%d: %.1f us  (%.2f B/px/ch algorithmic 8 -> %.2f TB/s)' %
-          (Cc, H, W, B, blocked, force_fft, t * 1e6, 8.0, px * 8 / t / 1e12))
+    print('lowpass C=%d %dx%d B=%d blocked=%d fft=%d ups=%d: %.1f us  (%.2f B/px/ch algorithmic 8 -> %.2f TB/s)' %
+          (Cc, H, W, B, blocked, force_fft, ups, t * 1e6, 8.0, px * 8 / t / 1e12))
 
 
 def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
