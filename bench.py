@@ -115,7 +115,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--cpu-sample', type=int, default=176, help='side of the CPU-baseline sample image (0: skip)')
+    ap.add_argument('--cpu-sample', type=int, default=208, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
     args = ap.parse_args()
 
