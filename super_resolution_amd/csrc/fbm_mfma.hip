@@ -97,6 +97,10 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
     const __half2 h = __floats2half2_rn(a, b);
     return *(const uint32_t*)&h;
 }
+// fp16 intermediates saturate instead of overflowing to infinity (NaN passes through)
+__device__ __forceinline__ uint32_t pack_h2_sat(float a, float b) {
+    return pack_h2(fminf(fmaxf(a, -65504.f), 65504.f), fminf(fmaxf(b, -65504.f), 65504.f));
+}
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
 
 // One 32 x 32 accumulator tile (rows = channels, column = this lane's output row) -> the 32 contiguous bytes of
@@ -107,8 +111,8 @@ __device__ __forceinline__ void tile_to_rows(const f32x16& acc, float scale, uin
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float a = acc[4 * q] * scale, b = acc[4 * q + 1] * scale, c = acc[4 * q + 2] * scale, d = acc[4 * q + 3] * scale;
-        P[q][0] = BF16 ? pack_bf2(a, b) : pack_h2(a, b);
-        P[q][1] = BF16 ? pack_bf2(c, d) : pack_h2(c, d);
+        P[q][0] = BF16 ? pack_bf2(a, b) : pack_h2_sat(a, b);
+        P[q][1] = BF16 ? pack_bf2(c, d) : pack_h2_sat(c, d);
     }
     // lanes l < 32 hold channels 8q + {0..3}, lanes l + 32 channels 8q + 4 + {0..3}: after the swaps the low lanes own
     // channels 0..15 and the high lanes channels 16..31 of their row
@@ -740,23 +744,23 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
         for (int w = 0; w < W; ++w) {
             const double v = basis_val(j, w, W);
             qwt[frag_index(j, w, W / 16)] = (h16)v;
-            qw[frag_index(w, j, pl->mf_ld_qw / 16)] = (h16)v;
+            qw[frag_index(w, j, pl->mf_ld_qw / 16)] = (h16)(4.0 * v);  // U is kept as U / 4
         }
     for (int n = 0; n < nh; ++n)
         for (int h = 0; h < H; ++h) {
             const double v = basis_val(n, h, H);
             pht[frag_index(n, h, H / 16)] = (h16)v;
-            ph[frag_index(h, n, pl->mf_ld_ph / 16)] = (h16)(16.0 * v);  // S is kept as S / 16 in fp16
+            ph[frag_index(h, n, pl->mf_ld_ph / 16)] = (h16)(16.0 * v);  // S is kept as S / 64, U as U / 4
         }
     memcpy(&host[o_win], win.data(), win.size() * sizeof(float));
     if (fold) {
         h16* qwf = (h16*)&host[o_qwf];
         for (int w = 0; w < W / 2; ++w)
             for (int c = 0; c < jw / 2; ++c) {  // k = c: cos coefficient 2c; k = 128 + c: sin coefficient 2c + 1
-                qwf[frag_index(w, c, 16)] = (h16)basis_val(2 * c, w, W);
-                qwf[frag_index(w, 128 + c, 16)] = (h16)basis_val(2 * c + 1, w, W);
+                qwf[frag_index(w, c, 16)] = (h16)(4.0 * basis_val(2 * c, w, W));
+                qwf[frag_index(w, 128 + c, 16)] = (h16)(4.0 * basis_val(2 * c + 1, w, W));
             }
-        for (int c = 0; c < jw / 2; ++c) qwf[frag_index(W / 2, c, 16)] = (h16)basis_val(2 * c, W / 2, W);
+        for (int c = 0; c < jw / 2; ++c) qwf[frag_index(W / 2, c, 16)] = (h16)(4.0 * basis_val(2 * c, W / 2, W));
     }
     char* dev = nullptr;
     SR_HIP(hipMalloc((void**)&dev, off));
@@ -825,7 +829,9 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     a1.NB = NB;
     a1.CG = CG;
     a1.nitems = H;
-    a1.scale = 1.0f;
+    // fp16 range of the intermediates: an orthonormal coefficient can reach sqrt(W) (sqrt(H W)) times the largest
+    // activation, so T and U are kept as T / 4, U / 4 and S as S / 64 (no overflow below |x| ~ 8000; the epilogues saturate)
+    a1.scale = 0.25f;
     SR_HIP(hipFuncSetAttribute((const void*)mf_analysis<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ana));
     mf_analysis<true><<<grid_for(H, 2), THREADS, lds_ana, st>>>(a1);
     SR_LAUNCH_CHECK();
@@ -848,7 +854,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     a2.scale = 1.0f / 16.0f;
     a2.pooled = pooled;
     a2.pooled_ld = pooled_ld;
-    a2.pool_scale = 1.0f / std::sqrt((float)H * (float)W);
+    a2.pool_scale = 4.0f / std::sqrt((float)H * (float)W);
     SR_HIP(hipFuncSetAttribute((const void*)mf_analysis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ana));
     mf_analysis<false><<<grid_for(jw, 2), THREADS, lds_ana, st>>>(a2);
     SR_LAUNCH_CHECK();

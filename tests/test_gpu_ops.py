@@ -575,3 +575,29 @@ def test_conv_mfma_bf16_bands_persample_ups(L):
     ref = ref_conv(xs, wt, **kw)
     # the modulated operand is rounded to bf16 once more before the MFMA: 2^-7 relative
     assert (got - ref).abs().max().item() < 2.0 ** -7 * max(1.0, ref.abs().max().item())
+
+
+def test_fbm_lowpass_mfma_large_activations(L):
+    """fp16 headroom of the DFT-as-GEMM intermediates: a 512 x 512 plane with a DC level of 3000 (coefficients up to
+    512 x that in an orthonormal basis) must come out finite and as accurate, relative to its size, as an O(1) plane."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(41)
+    x = bf(3000.0 + 1000.0 * torch.randn(1, 32, 512, 512, generator=g))
+    B, Cc, H, W = x.shape
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
+    xd = blocked(x, torch.bfloat16, 32)
+    bands = [torch.full((B, Cc // 32, H, W, 32), float('nan'), device='cuda:0', dtype=torch.bfloat16) for _ in range(3)]
+    pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+    L.check(lib.sr_fbm_lowpass(plan, 1, B, L.blocked_view(xd), 0, L.blocked_view(bands[0]), L.blocked_view(bands[1]),
+                               L.blocked_view(bands[2]), pooled.data_ptr(), Cc, ws.data_ptr(), ws.numel(), st(L)))
+    torch.cuda.synchronize()
+    lib.sr_fbm_plan_destroy(plan)
+    ref = fr.fbm_lowpass(x.double()).float()
+    for k in range(3):
+        got = unblocked(bands[k])
+        assert bool(torch.isfinite(got).all()), k
+        scale = ref[k].abs().max().item()
+        assert (got - ref[k]).abs().max().item() < 2.0 ** -7 * scale, k
+    assert (pooled.cpu() - x.mean(dim=(2, 3))).abs().max().item() < 1.0
