@@ -177,3 +177,42 @@ def test_tile_batching_equals_one_by_one():
     # torch's CPU conv picks its algorithm by batch size: allow one uint8 step of rounding difference
     assert np.abs(outs[0].astype(np.int32) - outs[1].astype(np.int32)).max() <= 1
     assert (outs[0] != outs[1]).mean() < 1e-3
+
+
+def test_checkpoint_conversion_matches_fdconv_init(tmp_path):
+    """super_resolution_amd.convert (reference tools/convert_to_fdconv.py:125-181 generalised to RRDBNet keys): the
+    spectrum it derives from a spatial weight is the one FDConv's own constructor derives (FDConv.py:604-623), it
+    inverts exactly, thin layers stay plain, containers are handled, and a plain checkpoint loads into an FDConv model."""
+    from super_resolution_amd import FDConv, RRDBNet, convert, replace_conv_with_fdconv
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(64, 32, 3, 1, 1)
+    w = conv.weight.data.clone()
+    layer = FDConv(64, 32, 3, 1, 1)
+    layer.weight = torch.nn.Parameter(w.clone())  # rerun the constructor's conversion on a known weight
+    layer.convert2dftweight()
+    d = convert.spatial_to_dft_weight(w)
+    assert d.shape == (1, 96, 97, 2) and torch.allclose(d, layer.dft_weight.data, atol=1e-7)
+    assert torch.allclose(convert.dft_weight_to_spatial(d, 32, 64), w, atol=1e-6)
+
+    plain = RRDBNet(1, 1, 4, 64, 1, 32)
+    sd = {k: v.clone() for k, v in plain.state_dict().items()}
+    new, converted = convert.convert_state_dict({'params_ema': sd})
+    assert set(new) == {'params_ema'} and len(converted) == 15 + 4  # 3 RDB x 5 convs + conv_body, conv_up1, conv_up2, conv_hr
+    assert 'conv_first.weight' in new['params_ema'] and 'conv_last.weight' in new['params_ema']  # thin: 1 channel
+    assert 'body.0.rdb1.conv1.dft_weight' in new['params_ema'] and 'body.0.rdb1.conv1.weight' not in new['params_ema']
+
+    fd = replace_conv_with_fdconv(RRDBNet(1, 1, 4, 64, 1, 32))
+    before = {k: v.clone() for k, v in fd.state_dict().items()}
+    convert.load_plain_into_fdconv(fd, {'params': sd})
+    after = fd.state_dict()
+    assert torch.allclose(after['body.0.rdb2.conv3.dft_weight'], convert.spatial_to_dft_weight(sd['body.0.rdb2.conv3.weight']))
+    assert torch.equal(after['conv_first.weight'], sd['conv_first.weight'])
+    assert torch.equal(after['body.0.rdb2.conv3.bias'], sd['body.0.rdb2.conv3.bias'])
+    k = 'body.0.rdb2.conv3.KSM_Global.fc.weight'
+    assert torch.equal(after[k], before[k])  # modulation parameters untouched
+
+    src, dst = tmp_path / 'plain.pth', tmp_path / 'fd.pth'
+    torch.save({'params': sd}, src)
+    assert convert.main(['convert', str(src), str(dst)]) == 0
+    back = torch.load(dst, map_location='cpu', weights_only=True)
+    assert 'body.0.rdb1.conv5.dft_weight' in back['params']
