@@ -193,7 +193,8 @@ int sr_rrdbnet_forward(sr_rrdbnet* net, int dtype, int io_dtype, int B, int Hin,
                        void* workspace, size_t workspace_bytes, void* stream);
 /* per-phase kernel-time attribution for bench.py: enables hipEvent timing around kernel groups
  * on the next forward; read back (ms) after a stream sync.  groups: 0 conv 1 lowpass 2 gates
- * 3 weightgen 4 layout */
+ * 3 weightgen 4 layout.  enable: 0 off, 1 every group, 2 the conv group only (an event pair costs ~4 us of stream
+ * time: 11 ms per config-2 forward with every group, 3 ms with the conv group alone) */
 int sr_rrdbnet_profile(sr_rrdbnet* net, int enable);
 int sr_rrdbnet_profile_read(sr_rrdbnet* net, float* ms5, long* launches5);
 

@@ -47,7 +47,7 @@ struct sr_rrdbnet {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
-    bool prof = false;
+    int prof = 0;  // 0 off, 1 every kernel group, 2 the conv group only
     std::vector<ProfEvent> events;
     size_t ev_used = 0;
 };
@@ -119,8 +119,11 @@ struct Run {
         return (cb && C % cb == 0) ? blocked_view(ws + off, C, npix, cb) : nhwc_view(ws + off, C, npix);
     }
 
+    bool prof_open = false;
     void prof_begin(int group, hipStream_t on = nullptr) {
-        if (!net->prof || rc != SR_OK) return;
+        prof_open = false;
+        if (!net->prof || rc != SR_OK || (net->prof == 2 && group != G_CONV)) return;
+        prof_open = true;
         if (!on) on = st;
         if (net->ev_used == net->events.size()) {
             ProfEvent e{};
@@ -131,7 +134,8 @@ struct Run {
         (void)hipEventRecord(net->events[net->ev_used].a, on);
     }
     void prof_end(hipStream_t on = nullptr) {
-        if (!net->prof || rc != SR_OK || net->ev_used >= net->events.size()) return;
+        if (!prof_open || !net->prof || rc != SR_OK || net->ev_used >= net->events.size()) return;
+        prof_open = false;
         (void)hipEventRecord(net->events[net->ev_used].b, on ? on : st);
         net->ev_used++;
     }
@@ -476,7 +480,7 @@ extern "C" int sr_rrdbnet_forward(sr_rrdbnet* n, int dtype, int io_dtype, int B,
 
 extern "C" int sr_rrdbnet_profile(sr_rrdbnet* n, int enable) {
     SR_REQUIRE(n);
-    n->prof = enable != 0;
+    n->prof = enable;
     n->ev_used = 0;
     return SR_OK;
 }
