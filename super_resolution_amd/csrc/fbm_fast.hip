@@ -281,8 +281,9 @@ __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int 
 // ---- rows forward of a nearest-2x upsampled tensor -----------------------------------------------
 // The source row s (N = W / 2 pixels) appears as rows 2h, 2h + 1 of the upsampled image, every pixel twice:
 //     FFT_W(up(s))[k] = (1 + w^k) FFT_N(s)[k mod N],   w = exp(-2 pi i / W),
-// so one N-point transform per SOURCE row serves two rows of T1 (a quarter of the butterflies of rows_fwd on the
-// upsampled rows).  tw = twiddles of length W (every second one is the N-point table).
+// so one N-point transform per SOURCE row serves two rows of the upsampled image (a quarter of the butterflies of
+// rows_fwd on the upsampled rows); T1 keeps the H / 2 distinct rows and cols<.., UPS = true> applies the same identity
+// along H.  tw = twiddles of length W (every second one is the N-point table).
 template <typename T, int N, int P, bool BLK>
 __global__ __launch_bounds__(THREADS) void rows_fwd_up(View x, int H, int PT, Inter im, const float2* __restrict__ tw, int a2,
                                                        float2* __restrict__ t1) {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void rows_fwd_up(View x, int H, int PT, In
     const int n2 = 2 * a2 - 1;
     const unsigned rowpix = (unsigned)hs * N;
     const T* xb = (const T*)x.p + (long)b * x.bs;
-    float2* t1b = t1 + ((long)b * im.NPG * n2 * H << im.QL);
+    float2* t1b = t1 + ((long)b * im.NPG * n2 * Hs << im.QL);  // T1 holds the Hs distinct rows only (see cols<.., UPS>)
     auto lf = [&](int idx, int p, int, int) {
         return (p0 + p < PT) ? Pair<T>::ld(xb + voff32(x, rowpix + idx, 2 * (p0 + p))) : make_float2(0.f, 0.f);
     };
@@ -308,21 +309,19 @@ __global__ __launch_bounds__(THREADS) void rows_fwd_up(View x, int H, int PT, In
         const float2 w = tw[idx];  // w^idx; w^(idx + N) = -w^idx
         if (idx < a2) {
             const float2 o = make_float2(v.x + v.x * w.x - v.y * w.y, v.y + v.x * w.y + v.y * w.x);
-            t1b[t1_off(im, p0 + p, idx, 2 * hs, n2, H)] = o;
-            t1b[t1_off(im, p0 + p, idx, 2 * hs + 1, n2, H)] = o;
+            t1b[t1_off(im, p0 + p, idx, hs, n2, Hs)] = o;
         }
         if (idx > N - a2) {
             const float2 o = make_float2(v.x - (v.x * w.x - v.y * w.y), v.y - (v.x * w.y + v.y * w.x));
             const int pos = kept_pos<W>(idx + N, a2);
-            t1b[t1_off(im, p0 + p, pos, 2 * hs, n2, H)] = o;
-            t1b[t1_off(im, p0 + p, pos, 2 * hs + 1, n2, H)] = o;
+            t1b[t1_off(im, p0 + p, pos, hs, n2, Hs)] = o;
         }
     };
     fft<N, P, false, BLK, 1, false, 0, 0>(buf, twl, lf, sl);
 }
 
 // ---- columns: forward, mask, inverse x3 ------------------------------------------------------
-template <int N, int P, bool BLK, bool PZ>
+template <int N, int P, bool BLK, bool PZ, bool UPS = false>
 __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
                                                 int a8, const float* __restrict__ rowmask,
                                                 const float2* __restrict__ t1, float2* __restrict__ y2,
@@ -337,18 +336,29 @@ __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, cons
     const int b = bx / n2, idx = bx % n2;
     const int p0 = by * P;
     const int col = idx < a2 ? idx : idx + (W - n2);  // full-spectrum column of this block
-    const float2* t1b = t1 + ((long)b * im.NPG * n2 * H << im.QL);
+    // UPS: T1 holds the H / 2 rows of a tensor that is nearest-upsampled along H as well; its column spectrum is
+    // (1 + w^k) F[k mod H/2] with F the half-length transform (w = exp(-2 pi i / H)).  The half-length twiddles live in the
+    // upper half of `buf` while the forward transform uses the lower one.
+    constexpr int NF = UPS ? N / 2 : N;
+    const float2* t1b = t1 + ((long)b * im.NPG * n2 * NF << im.QL);
     auto lf = [&](int h, int p, int, int) {
-        return (p0 + p < PT) ? t1b[t1_off(im, p0 + p, idx, h, n2, H)] : make_float2(0.f, 0.f);
+        return (p0 + p < PT) ? t1b[t1_off(im, p0 + p, idx, h, n2, NF)] : make_float2(0.f, 0.f);
     };
-    auto s_lds = [&](int r, int p, float2 v) { buf[lds_idx<N, P, BLK>(r, p)] = v; };
+    auto s_lds = [&](int r, int p, float2 v) { buf[lds_idx<NF, P, BLK>(r, p)] = v; };
     // forward: the last pass stores back into LDS
-    fft<N, P, false, BLK, 1, true, 0, fwd_oz<N, PZ>()>(buf, twl, lf, s_lds);
+    if constexpr (UPS) {
+        float2* twh = buf + NF * P;
+        for (int i = threadIdx.x; i < NF; i += THREADS) twh[i] = twl[2 * i];
+        __syncthreads();
+        fft<NF, P, false, BLK, 1, true, 0, 0>(buf, twh, lf, s_lds);
+    } else {
+        fft<N, P, false, BLK, 1, true, 0, fwd_oz<N, PZ>()>(buf, twl, lf, s_lds);
+    }
     __syncthreads();
     if (pooled && idx == 0 && threadIdx.x < P && p0 + threadIdx.x < PT) {
         const int c = 2 * (p0 + threadIdx.x);
-        const float inv = 1.0f / ((float)H * (float)W);
-        const float2 dc = buf[lds_idx<N, P, BLK>(0, threadIdx.x)];
+        const float inv = (UPS ? 2.0f : 1.0f) / ((float)H * (float)W);
+        const float2 dc = buf[lds_idx<NF, P, BLK>(0, threadIdx.x)];
         if (c < C) pooled[(long)b * pooled_ld + c] = dc.x * inv;
         if (c + 1 < C) pooled[(long)b * pooled_ld + c + 1] = dc.y * inv;
     }
@@ -364,8 +374,15 @@ __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, cons
         int p, j;
         item_to_pj<P, NR0, BLK>(i, p, j);
 #pragma unroll
-        for (int t = 0; t < R0; ++t)
-            sreg[q][t] = (NB % THREADS == 0 || i < NB) ? buf[lds_idx<N, P, BLK>(j + t * NR0, p)] : make_float2(0.f, 0.f);
+        for (int t = 0; t < R0; ++t) {
+            const int k = j + t * NR0;
+            float2 v = (NB % THREADS == 0 || i < NB) ? buf[lds_idx<NF, P, BLK>(UPS ? (k & (NF - 1)) : k, p)] : make_float2(0.f, 0.f);
+            if constexpr (UPS) {
+                const float2 w = twl[k];
+                v = make_float2(v.x + v.x * w.x - v.y * w.y, v.y + v.x * w.y + v.y * w.x);
+            }
+            sreg[q][t] = v;
+        }
     }
     const int variant = (col == 0 || 2 * col == W) ? 2 : (2 * col < W ? 0 : 1);
     const int ak[3] = {a2, a4, a8};
@@ -468,10 +485,10 @@ inline int pairs_for_rt(int n) { return pairs_for(n); }
 int g_no_ups_shortcut = 0;  // debug hook
 
 template <typename T, int N, bool BLK>
-static int launch_rows_fwd(View x, int ups, int B, int H, int PT, Inter im, const sr_fbm_plan* pl, float2* t1,
+static int launch_rows_fwd(View x, int ups, bool shortcut, int B, int H, int PT, Inter im, const sr_fbm_plan* pl, float2* t1,
                            hipStream_t st) {
     if constexpr (N >= 128) {
-        if (ups == 1 && pl->half[0] <= N / 2 && !g_no_ups_shortcut) {  // one half-length transform per source row
+        if (shortcut) {  // one half-length transform per source row
             constexpr int NS = N / 2, PS = pairs_for(NS);
             const size_t ldss = (size_t)NS * PS * sizeof(float2) + (size_t)NS * sizeof(float2);
             SR_HIP(hipFuncSetAttribute((const void*)rows_fwd_up<T, NS, PS, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
@@ -517,23 +534,30 @@ static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inte
 }
 
 template <int N, bool BLK>
-static int launch_cols(int B, int W, int PT, int C, Inter im, const sr_fbm_plan* pl, const float2* t1, float2* y2,
+static int launch_cols(bool shortcut, int B, int W, int PT, int C, Inter im, const sr_fbm_plan* pl, const float2* t1, float2* y2,
                        float2* y4, float2* y8, float* pooled, int pooled_ld, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
     bool pz = first_radix(N) == 8;  // every variant of every row mask must leave the standard ranges empty
     for (int kv = 0; kv < 9; ++kv) pz = pz && (pl->row_zmask[kv] & (kv >= 6 ? 0x7e : 0x3c)) == (kv >= 6 ? 0x7e : 0x3c);
-    if (pz) {
-        SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        cols<N, P, BLK, true><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1],
-                                                                             pl->half[2], pl->rowmask, t1, y2, y4, y8, pooled,
-                                                                             pooled_ld, C);
-    } else {
-        SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        cols<N, P, BLK, false><<<dim3(B * pl->n[0], cdiv(PT, P)), THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1],
-                                                                             pl->half[2], pl->rowmask, t1, y2, y4, y8, pooled,
-                                                                             pooled_ld, C);
+    const dim3 grid(B * pl->n[0], cdiv(PT, P));
+#define SR_COLS(PZ_, UPS_)                                                                                                   \
+    do {                                                                                                                     \
+        SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK, PZ_, UPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        cols<N, P, BLK, PZ_, UPS_><<<grid, THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1], pl->half[2],    \
+                                                             pl->rowmask, t1, y2, y4, y8, pooled, pooled_ld, C);             \
+    } while (0)
+    if constexpr (N >= 128) {
+        if (shortcut) {
+            if (pz) SR_COLS(true, true);
+            else SR_COLS(false, true);
+            SR_LAUNCH_CHECK();
+            return SR_OK;
+        }
     }
+    if (pz) SR_COLS(true, false);
+    else SR_COLS(false, false);
+#undef SR_COLS
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -567,12 +591,14 @@ static int run_all(const sr_fbm_plan* pl, int B, View x, int ups, View l2, View 
     float2* y4 = y2 + (size_t)B * H * n2 * PTP;
     float2* y8 = y4 + (size_t)B * H * n4 * PTP;
     const bool blk_c = im.Q == 4;  // 4-pair groups: butterflies of one group on consecutive lanes
+    // nearest-2x upsampled source: half-length transforms along both axes, T1 keeps the H / 2 distinct rows
+    const bool shortcut = ups == 1 && H >= 128 && W >= 128 && pl->half[0] <= W / 2 && !g_no_ups_shortcut;
     int rc = SR_OK;
-    if (blk_x) { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, true>(x, ups, B, H, PT, im, pl, t1, st))); }
-    else { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, false>(x, ups, B, H, PT, im, pl, t1, st))); }
+    if (blk_x) { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, true>(x, ups, shortcut, B, H, PT, im, pl, t1, st))); }
+    else { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, false>(x, ups, shortcut, B, H, PT, im, pl, t1, st))); }
     if (rc != SR_OK) return rc;
-    if (blk_c) { SR_DISPATCH_N(H, rc = (launch_cols<NN, true>(B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
-    else { SR_DISPATCH_N(H, rc = (launch_cols<NN, false>(B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
+    if (blk_c) { SR_DISPATCH_N(H, rc = (launch_cols<NN, true>(shortcut, B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
+    else { SR_DISPATCH_N(H, rc = (launch_cols<NN, false>(shortcut, B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
     if (rc != SR_OK) return rc;
     if (blk_o) { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, true>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, st))); }
     else { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, false>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, st))); }

@@ -41,6 +41,17 @@ def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0, force_fft=1, ups=0):
     pooled = torch.empty(B, Cc, device=dev)
     ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device=dev)
 
+    checksum = []
+    for no_sc in ((0, 1) if ups else (0,)):  # A/B of the upsample shortcut inside one process
+        lib.sr_debug_no_ups_shortcut(no_sc)
+        run_once = lambda: L.check(lib.sr_fbm_lowpass(plan, 1, B, mk(x), ups, mk(bands[0]), mk(bands[1]), mk(bands[2]), pooled.data_ptr(),
+                                                      Cc, ws.data_ptr(), ws.numel(), st))  # noqa: E731
+        tt = timeit(run_once, reps)
+        checksum.append([float(b.float().abs().mean()) for b in bands] + [float(pooled.abs().mean())])
+        if ups:
+            print('  ups shortcut %s: %.1f us  checksums %s' % ('off' if no_sc else 'on', tt * 1e6, checksum[-1]))
+    lib.sr_debug_no_ups_shortcut(0)
+
     def run():
         L.check(lib.sr_fbm_lowpass(plan, 1, B, mk(x), ups, mk(bands[0]), mk(bands[1]), mk(bands[2]), pooled.data_ptr(), Cc,
                                    ws.data_ptr(), ws.numel(), st))
