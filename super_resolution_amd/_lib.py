@@ -82,6 +82,7 @@ _SIGS = {
     'sr_debug_force_generic_fft': (None, [C.c_int]),
     'sr_debug_force_fft_lowpass': (None, [C.c_int]),
     'sr_debug_no_ups_shortcut': (None, [C.c_int]),
+    'sr_debug_gates_no_direct': (None, [C.c_int]),
     'sr_debug_mfma_no_fold': (None, [C.c_int]),
     'sr_debug_force_generic_gates': (None, [C.c_int]),
 }

@@ -2,6 +2,7 @@
 // Cin -> 3 output planes: a bandwidth-shaped kernel.  One workgroup = one 16x16 pixel tile; the
 // halo tile of a few channels is staged in LDS plane-major so that the 9-tap reads of
 // neighbouring lanes hit neighbouring banks.
+#include <cstdlib>
 #include <algorithm>
 
 #include "common.h"
@@ -321,10 +322,166 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct form of the same accumulation (32- and 64-channel segments): D[4 * consumer + gate][pixel] as ONE GEMM over
+// K = 9 taps x C channels, all consumers at once.  The haloed activation tile (10 x 34 slots) is staged in LDS once per
+// tile and the B fragments are read at the 9 shifted positions; the weight rows (4 per consumer, the 4th zero) sit in
+// LDS.  No T image, no per-consumer barrier: two barriers per tile.  Each wave owns two pixel rows of the 8 x 32 tile.
+// Lane (n = lane & 31, hk = lane >> 5) ends up with the three logits of pixel n for the consumers 2 j + hk.
+// ---------------------------------------------------------------------------------------------
+template <int NC, int CK>
+__global__ __launch_bounds__(256) void fbm_gates_acc_direct(View seg, int B, int H, int W, GateConsList cl) {
+    constexpr int C = 16 * CK;
+    constexpr int XS = C * 2 + 16;       // bytes per slot of the activation tile (padded: conflict-free 16-byte reads)
+    constexpr int KA = 9 * C;            // K of a weight row
+    constexpr int AS = KA * 2 + 16;      // bytes per weight row
+    constexpr int NROW = 4 * NC;
+    constexpr int CP = C / 8;            // 16-byte parts per slot
+    constexpr int NCHUNK = GSLOTS * CP;
+    constexpr int NPRE = (NCHUNK + 255) / 256;
+    constexpr int NJ = (NC + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char glds[];
+    char* X = glds;                // [GSLOTS][XS]
+    char* A = glds + GSLOTS * XS;  // [NROW][AS]
+    const int tilesx = (W + GMW - 1) / GMW;
+    const unsigned tiles = (unsigned)tilesx * ((H + GMH - 1) / GMH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hk = lane >> 5;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        const float* w0 = cl.c[ci].w[0];
+        const float* w1 = cl.c[ci].w[1];
+        const float* w2 = cl.c[ci].w[2];
+        for (int it = tid; it < 4 * KA; it += 256) {
+            const int g = it / KA, k = it - g * KA;
+            const int tap = k / C, c = k - tap * C;
+            const float* wk = g == 0 ? w0 : (g == 1 ? w1 : w2);
+            const float v = g < 3 ? wk[(long)c * 9 + tap] : 0.f;
+            *(bf16_t*)(A + (ci * 4 + g) * AS + k * 2) = f32_to_bf16(v);
+        }
+    }
+    const unsigned total = tiles * (unsigned)B;
+    const unsigned xj = blockIdx.x & 7u, q8 = total >> 3, r8 = total & 7u;
+    const unsigned wstart = xj * q8 + (xj < r8 ? xj : r8), wend = wstart + q8 + (xj < r8 ? 1u : 0u);
+    const unsigned wstride = (gridDim.x - xj + 7u) >> 3;
+    unsigned lin = wstart + (blockIdx.x >> 3);
+    if (lin >= wend) return;  // block-uniform
+    // chunk q of the haloed tile -> (slot, part); loads are clamped into the image, the stash writes zeros outside it
+    auto fetch = [&](unsigned l, uint4 (&pre)[NPRE]) {
+        const int tile = l % tiles, b = l / tiles;
+        const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int q = min(tid + 256 * i, NCHUNK - 1);
+            const int slot = q / CP, part = q - slot * CP;
+            const int py = slot / GPW, px = slot - py * GPW;
+            const int h = min(max(h0 + py - 1, 0), H - 1), w = min(max(w0p + px - 1, 0), W - 1);
+            pre[i] = *(const uint4*)((const bf16_t*)seg.p + voff(seg, b, (long)h * W + w, part * 8));
+        }
+    };
+    auto stash = [&](unsigned l, const uint4 (&pre)[NPRE]) {
+        const int tile = l % tiles;
+        const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int q = tid + 256 * i;
+            if (q >= NCHUNK) break;
+            const int slot = q / CP, part = q - slot * CP;
+            const int py = slot / GPW, px = slot - py * GPW;
+            const int h = h0 + py - 1, w = w0p + px - 1;
+            const bool in = h >= 0 && h < H && w >= 0 && w < W;
+            *(uint4*)(X + slot * XS + part * 16) = in ? pre[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 pre[NPRE];
+    fetch(lin, pre);
+    const int ra = min(n, NROW - 1);
+    for (; lin < wend; lin += wstride) {
+        const int tile = lin % tiles, b = lin / tiles;
+        const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
+        __syncthreads();  // the previous tile's fragment reads are done (first tile: nothing pending)
+        stash(lin, pre);
+        // this tile's running logits first, then the next tile's activations (in-order counters: the logits are needed
+        // first); all loads unconditional and clamped, issued before any store of this tile
+        Logit3 lgp[2][NJ];
+        long pix[2];
+        bool inside[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int h = h0 + wave * 2 + p, w = w0p + n;
+            inside[p] = h < H && w < W;
+            const long pin = (long)min(h, H - 1) * W + min(w, W - 1);
+            pix[p] = (long)b * H * W + pin;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const GateCons& g0 = cl.c[2 * j];
+                const GateCons& g1 = cl.c[2 * j + 1 < NC ? 2 * j + 1 : 2 * j];
+                const float* lp = hk ? g1.logits : g0.logits;
+                const int first = hk ? g1.first : g0.first;
+                // a consumer that starts from its bias reads (and ignores) 12 bytes of the segment itself: always valid
+                const char* src = first ? (const char*)((const bf16_t*)seg.p + voff(seg, b, pin, 0)) : (const char*)(lp + 3 * pix[p]);
+                lgp[p][j] = *(const Logit3*)src;
+            }
+        }
+        fetch(min(lin + wstride, wend - 1), pre);  // past the end: any valid tile, dropped
+        __syncthreads();
+        g_float16 acc[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int ks = 0; ks < CK; ++ks) {
+                const g_short8 afrag = *(const g_short8*)(A + ra * AS + (tap * C + ks * 16 + hk * 8) * 2);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int slot = (wave * 2 + p + tap / 3) * GPW + n + tap % 3;
+                    const g_short8 bfrag = *(const g_short8*)(X + slot * XS + (ks * 16 + hk * 8) * 2);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[p], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const GateCons& g0 = cl.c[2 * j];
+                const GateCons& g1 = cl.c[2 * j + 1 < NC ? 2 * j + 1 : 2 * j];
+                const bool mine = inside[p] && (2 * j + 1 < NC || !hk);
+                const int first = hk ? g1.first : g0.first;
+                float lg[3];
+                lg[0] = first ? (hk ? g1.b[0][0] : g0.b[0][0]) : lgp[p][j].x;
+                lg[1] = first ? (hk ? g1.b[1][0] : g0.b[1][0]) : lgp[p][j].y;
+                lg[2] = first ? (hk ? g1.b[2][0] : g0.b[2][0]) : lgp[p][j].z;
+                lg[0] += acc[p][4 * j + 0];
+                lg[1] += acc[p][4 * j + 1];
+                lg[2] += acc[p][4 * j + 2];
+                float* gp = hk ? g1.gates : g0.gates;
+                float* lo = hk ? g1.logits : g0.logits;
+                if (mine) {
+                    if (gp) {
+                        float4 g;
+                        g.x = 2.0f / (1.0f + expf(-lg[0]));
+                        g.y = 2.0f / (1.0f + expf(-lg[1]));
+                        g.z = 2.0f / (1.0f + expf(-lg[2]));
+                        g.w = 0.f;
+                        ((float4*)gp)[pix[p]] = g;
+                    } else {
+                        ((Logit3*)lo)[pix[p]] = Logit3{lg[0], lg[1], lg[2]};
+                    }
+                }
+            }
+        }
+    }
+}
+
+int g_gates_no_direct = 0;  // debug hook (A/B inside one process)
+
 int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, hipStream_t st) {
     if (cl.n < 1 || cl.n > SR_MAX_GATE_CONSUMERS) return SR_ERR_ARG;
     if (seg.C % 16 || seg.C > 64 || !view_vec_ok(seg, 8)) return SR_NOT_ELIGIBLE;
-    const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + (size_t)cl.n * 32 * (seg.C * 2 + 16);
     const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     static int ncu = 0;
@@ -333,6 +490,40 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
         SR_HIP(hipGetDevice(&dev));
         SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
+    // direct form: 64-channel segments (278 vs 405 us with five consumers at batch 16 of 512 x 512); at 32 channels the
+    // T-image kernel below is as fast or faster (211 vs 246 us with four consumers), SR_AMD_GATES_DIRECT=1 forces it
+    static const bool direct32 = getenv("SR_AMD_GATES_DIRECT") && atoi(getenv("SR_AMD_GATES_DIRECT")) == 1;
+    if ((seg.C == 64 || (seg.C == 32 && direct32)) && !g_gates_no_direct) {
+        const int ck = seg.C / 16;
+        const size_t ldsd = (size_t)GSLOTS * (seg.C * 2 + 16) + (size_t)4 * cl.n * (9 * seg.C * 2 + 16);
+        static int resident[SR_MAX_GATE_CONSUMERS + 1][2];  // persistent grid = resident workgroups
+        int& per_cu = resident[cl.n][ck == 4];
+#define SR_GATES_DIRECT_V(NC, CK)                                                                                        \
+    do {                                                                                                                 \
+        const void* fn = (const void*)fbm_gates_acc_direct<NC, CK>;                                                      \
+        if (!per_cu) {                                                                                                   \
+            SR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));                      \
+            SR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, ldsd));                                \
+            per_cu = std::max(1, std::min(4, per_cu));                                                                   \
+        }                                                                                                                \
+        const dim3 grid((unsigned)std::min<long>(nblk, (long)per_cu * ncu));                                             \
+        fbm_gates_acc_direct<NC, CK><<<grid, 256, ldsd, st>>>(seg, B, H, W, cl);                                         \
+    } while (0)
+#define SR_GATES_DIRECT(NC)                                                                                              \
+    case NC:                                                                                                             \
+        if (ck == 2) SR_GATES_DIRECT_V(NC, 2);                                                                           \
+        else SR_GATES_DIRECT_V(NC, 4);                                                                                   \
+        break;
+        switch (cl.n) {
+            SR_GATES_DIRECT(1) SR_GATES_DIRECT(2) SR_GATES_DIRECT(3) SR_GATES_DIRECT(4) SR_GATES_DIRECT(5) SR_GATES_DIRECT(6)
+            SR_GATES_DIRECT(7) SR_GATES_DIRECT(8)
+        }
+#undef SR_GATES_DIRECT
+#undef SR_GATES_DIRECT_V
+        SR_LAUNCH_CHECK();
+        return SR_OK;
+    }
+    const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + (size_t)cl.n * 32 * (seg.C * 2 + 16);
     const long per_cu = std::max<long>(1, std::min<long>(4, (160 * 1024) / (long)lds));
     const dim3 grid((unsigned)std::min<long>(nblk, per_cu * ncu));
 #define SR_GATES_ACC(NC)                                                                                                 \
@@ -429,3 +620,4 @@ extern "C" int sr_fbm_gates_accumulate(int dtype, int B, int H, int W, sr_view s
 }
 
 extern "C" void sr_debug_force_generic_gates(int on) { sr::g_force_generic_gates = on; }
+extern "C" void sr_debug_gates_no_direct(int on) { sr::g_gates_no_direct = on; }
