@@ -19,10 +19,31 @@ inline int hip_fail(hipError_t e) {
         if (_e != hipSuccess) return sr::hip_fail(_e); \
     } while (0)
 #define SR_LAUNCH_CHECK() SR_HIP(hipGetLastError())
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device, raised when a launch asks for more: the call
+// costs microseconds of host time and a forward issues thousands of launches (small inputs are launch-bound)
+#define SR_LDS_ATTR(bytes, ...)                                           \
+    do {                                                                  \
+        static sr::LdsAttr attr_;                                         \
+        SR_HIP(sr::lds_attr(attr_, (const void*)(__VA_ARGS__), (size_t)(bytes))); \
+    } while (0)
 #define SR_REQUIRE(cond)            \
     do {                            \
         if (!(cond)) return SR_ERR_ARG; \
     } while (0)
+
+struct LdsAttr {
+    int set[16] = {};
+};
+inline hipError_t lds_attr(LdsAttr& a, const void* fn, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int& have = a.set[dev & 15];
+    if (have && have >= (int)bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = (int)bytes > 0 ? (int)bytes : 1;
+    return e;
+}
 
 typedef uint16_t bf16_t;  // raw bits
 

@@ -132,12 +132,104 @@ __device__ __forceinline__ void fft_pass_pp(const float2* __restrict__ src, floa
     }
 }
 
+// The same pass with whole radix-R butterflies per work item (R a compile-time constant): butterfly j of PP consecutive
+// signals reads its R operands once (source points j + t N/R), applies the pass twiddles w^(t k tstep), and writes the R
+// outputs of the small DFT to ((j / Ns) R + u) Ns + k, k = j % Ns.  One integer division per butterfly instead of three per
+// output point, and one LDS read per point and pass instead of R.
+template <bool INV, int PP, int R>
+__device__ __forceinline__ void fft_pass_bfly(const float2* __restrict__ src, float2* __restrict__ dst, int N, int Ns, int P,
+                                              const float2* __restrict__ tw, const float* __restrict__ premul) {
+    const int NR = N / R;
+    const int tstep = NR / Ns;
+    const int PG = P / PP;  // a power of two
+    const int pgs = 31 - __clz(PG);
+    for (int it = threadIdx.x; it < NR * PG; it += blockDim.x) {
+        const int pg = it & (PG - 1);
+        const int j = it >> pgs;
+        const int jhi = j / Ns, k = j - jhi * Ns;
+        float2 v[R][PP];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int si = j + t * NR;
+            float2 w = tw[t * k * tstep];  // < N
+            if (INV) w.y = -w.y;
+            if (premul) {
+                const float m = premul[si];
+                w.x *= m;
+                w.y *= m;
+            }
+            const float2* sp = src + si * P + pg * PP;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) v[t][i] = t == 0 && !premul ? sp[i] : cmul(sp[i], w);
+        }
+        float2* dp = dst + (jhi * R * Ns + k) * P + pg * PP;
+        if constexpr (R == 2) {
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                dp[i] = make_float2(v[0][i].x + v[1][i].x, v[0][i].y + v[1][i].y);
+                dp[Ns * P + i] = make_float2(v[0][i].x - v[1][i].x, v[0][i].y - v[1][i].y);
+            }
+        } else if constexpr (R == 4) {
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const float2 a = make_float2(v[0][i].x + v[2][i].x, v[0][i].y + v[2][i].y);
+                const float2 b = make_float2(v[0][i].x - v[2][i].x, v[0][i].y - v[2][i].y);
+                const float2 c = make_float2(v[1][i].x + v[3][i].x, v[1][i].y + v[3][i].y);
+                float2 d = make_float2(v[1][i].x - v[3][i].x, v[1][i].y - v[3][i].y);
+                d = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);  // times w_4 (forward: -i)
+                dp[i] = make_float2(a.x + c.x, a.y + c.y);
+                dp[Ns * P + i] = make_float2(b.x + d.x, b.y + d.y);
+                dp[2 * Ns * P + i] = make_float2(a.x - c.x, a.y - c.y);
+                dp[3 * Ns * P + i] = make_float2(b.x - d.x, b.y - d.y);
+            }
+        } else {
+            // one output at a time (R x PP operands stay in registers, PP accumulators); w_R^(t u) comes from the LDS table
+#pragma unroll 1
+            for (int u = 0; u < R; ++u) {
+                float2 acc[PP];
+#pragma unroll
+                for (int i = 0; i < PP; ++i) acc[i] = v[0][i];
+                int m = 0;
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    m += u;
+                    if (m >= R) m -= R;
+                    float2 o = tw[m * NR];
+                    if (INV) o.y = -o.y;
+#pragma unroll
+                    for (int i = 0; i < PP; ++i) {
+                        acc[i].x += v[t][i].x * o.x - v[t][i].y * o.y;
+                        acc[i].y += v[t][i].x * o.y + v[t][i].y * o.x;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PP; ++i) dp[u * Ns * P + i] = acc[i];
+            }
+        }
+    }
+}
+
+template <bool INV, int PP>
+__device__ __forceinline__ void fft_pass_r(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
+                                           int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+    switch (R) {  // block-uniform
+        case 2: fft_pass_bfly<INV, PP, 2>(src, dst, N, Ns, P, tw, premul); break;
+        case 3: fft_pass_bfly<INV, PP, 3>(src, dst, N, Ns, P, tw, premul); break;
+        case 4: fft_pass_bfly<INV, PP, 4>(src, dst, N, Ns, P, tw, premul); break;
+        case 5: fft_pass_bfly<INV, PP, 5>(src, dst, N, Ns, P, tw, premul); break;
+        case 7: fft_pass_bfly<INV, (PP < 2 ? PP : 2), 7>(src, dst, N, Ns, P, tw, premul); break;  // 7 x PP operands in registers
+        default: fft_pass_pp<INV, PP>(src, dst, N, R, Ns, P, tw, premul);  // larger prime factors: one output per item
+    }
+}
+
 template <bool INV>
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
                                          int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
-    if ((P & 3) == 0) fft_pass_pp<INV, 4>(src, dst, N, R, Ns, P, tw, premul);
-    else if ((P & 1) == 0) fft_pass_pp<INV, 2>(src, dst, N, R, Ns, P, tw, premul);
-    else fft_pass_pp<INV, 1>(src, dst, N, R, Ns, P, tw, premul);
+    // signals per work item: as many as leave at least one butterfly for every thread of the block
+    const int bf = N / R, nt = blockDim.x;
+    if ((P & 3) == 0 && bf * (P >> 2) >= nt) fft_pass_r<INV, 4>(src, dst, N, R, Ns, P, tw, premul);
+    else if ((P & 1) == 0 && bf * (P >> 1) >= nt) fft_pass_r<INV, 2>(src, dst, N, R, Ns, P, tw, premul);
+    else fft_pass_r<INV, 1>(src, dst, N, R, Ns, P, tw, premul);
 }
 
 // Runs all passes; returns the buffer that holds the result.  bufA holds the input.  When
@@ -163,7 +255,7 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 
 // ---- kernel 1: forward FFT along W ---------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int W, int C, int PT, int P, Radix rx,
+__global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int H, int W, int C, int PT, int P, Radix rx,
                                                     const float2* __restrict__ tw, const int* __restrict__ cols, int n2,
                                                     float2* __restrict__ t1) {
     float2* bufA = (float2*)smem;
@@ -173,6 +265,7 @@ __global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int 
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int p0 = blockIdx.y * P;
     const int Ws = W >> ups;
+    #pragma unroll 8
     for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
         const int p = it % P, w = it / P;
         const int c = 2 * (p0 + p);
@@ -185,6 +278,7 @@ __global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int 
     __syncthreads();
     const float2* res = fft_run<false>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
     // t1[b][idx][h][PT]
+    #pragma unroll 8
     for (int it = threadIdx.x; it < n2 * P; it += blockDim.x) {
         const int p = it % P, idx = it / P;
         if (p0 + p < PT) t1[(((long)b * n2 + idx) * H + h) * PT + p0 + p] = res[cols[idx] * P + p];
@@ -192,7 +286,7 @@ __global__ __launch_bounds__(256) void fbm_rows_fwd(View x, int ups, int H, int 
 }
 
 // ---- kernel 2: FFT along H, row masks, inverse FFT along H ----------------------------------
-__global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Radix rx, const float2* __restrict__ tw,
+__global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Radix rx, const float2* __restrict__ tw,
                                                 const int* __restrict__ colinfo, int n2, int n4, int n8,
                                                 const float* __restrict__ rowmask, const float2* __restrict__ t1,
                                                 float2* __restrict__ y2, float2* __restrict__ y4,
@@ -206,6 +300,7 @@ __global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Rad
     const int b = blockIdx.x / n2, idx = blockIdx.x % n2;
     const int p0 = blockIdx.y * P;
     const float2* col = t1 + ((long)b * n2 + idx) * H * PT;
+    #pragma unroll 8
     for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
         const int p = it % P, h = it / P;
         buf0[it] = (p0 + p < PT) ? col[(long)h * PT + p0 + p] : make_float2(0.f, 0.f);
@@ -228,6 +323,7 @@ __global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Rad
         const float* rm = rowmask + (k * 3 + variant) * H;
         const float2* res = fft_run<true>(S, buf2, other, true, H, rx, P, twl, rm);
         float2* y = ys[k];
+        #pragma unroll 8
         for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
             const int p = it % P, h = it / P;
             if (p0 + p < PT) y[(((long)b * H + h) * nk[k] + kidx[k]) * PT + p0 + p] = res[it];
@@ -238,7 +334,7 @@ __global__ __launch_bounds__(256) void fbm_cols(int H, int W, int PT, int P, Rad
 
 // ---- kernel 3: inverse FFT along W, write the three low-pass tensors ------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, int H, int W, int C, int PT, int P,
+__global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, int H, int W, int C, int PT, int P,
                                                     Radix rx, const float2* __restrict__ tw,
                                                     const int* __restrict__ cols2, const int* __restrict__ cols4,
                                                     const int* __restrict__ cols8, int n2, int n4, int n8,
@@ -259,12 +355,14 @@ __global__ __launch_bounds__(256) void fbm_rows_inv(View l2, View l4, View l8, i
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) bufA[it] = make_float2(0.f, 0.f);
         __syncthreads();
         const float2* yr = ys[k] + ((long)b * H + h) * nk[k] * PT;
+        #pragma unroll 8
         for (int it = threadIdx.x; it < nk[k] * P; it += blockDim.x) {
             const int p = it % P, i = it / P;
             if (p0 + p < PT) bufA[ck[k][i] * P + p] = yr[(long)i * PT + p0 + p];
         }
         __syncthreads();
         const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
+        #pragma unroll 8
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
             const int p = it % P, w = it / P;
             const int c = 2 * (p0 + p);
@@ -315,27 +413,35 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     const int Pw = pl->Pw, Ph = pl->Ph;
     const size_t lds_w = (2ul * W * Pw + W) * sizeof(float2), lds_h = (3ul * H * Ph + H) * sizeof(float2);  // buffers + twiddles
     dim3 g1(B * H, cdiv(PT, Pw)), g2(B * n2, cdiv(PT, Ph));
+    // threads per block: about 16 waves per CU whatever the LDS footprint allows to be resident (1, 2 or >= 4 blocks)
+    static const int forced = getenv("SR_AMD_GENERIC_THREADS") ? atoi(getenv("SR_AMD_GENERIC_THREADS")) : 0;
+    auto threads_for = [](size_t lds) {
+        if (forced == 256 || forced == 512 || forced == 1024) return forced;
+        const size_t resident = (160ul * 1024) / lds;
+        return resident >= 4 ? 256 : (resident >= 2 ? 512 : 1024);
+    };
+    const int tw_ = threads_for(lds_w), th_ = threads_for(lds_h);
     if (dtype == SR_F32) {
-        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
-        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_inv<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        SR_LDS_ATTR(lds_w, fbm_rows_fwd<float>);
+        SR_LDS_ATTR(lds_w, fbm_rows_inv<float>);
     } else {
-        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_fwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
-        SR_HIP(hipFuncSetAttribute((const void*)fbm_rows_inv<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        SR_LDS_ATTR(lds_w, fbm_rows_fwd<bf16_t>);
+        SR_LDS_ATTR(lds_w, fbm_rows_inv<bf16_t>);
     }
-    SR_HIP(hipFuncSetAttribute((const void*)fbm_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+    SR_LDS_ATTR(lds_h, fbm_cols);
     if (dtype == SR_F32)
-        fbm_rows_fwd<float><<<g1, 256, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+        fbm_rows_fwd<float><<<g1, tw_, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
     else
-        fbm_rows_fwd<bf16_t><<<g1, 256, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+        fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
     SR_LAUNCH_CHECK();
-    fbm_cols<<<g2, 256, lds_h, st>>>(H, W, PT, Ph, rh, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
+    fbm_cols<<<g2, th_, lds_h, st>>>(H, W, PT, Ph, rh, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
                                      pooled, pooled_ld, C);
     SR_LAUNCH_CHECK();
     if (dtype == SR_F32)
-        fbm_rows_inv<float><<<g1, 256, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+        fbm_rows_inv<float><<<g1, tw_, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
                                                     pl->cols8, n2, n4, n8, y2, y4, y8);
     else
-        fbm_rows_inv<bf16_t><<<g1, 256, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+        fbm_rows_inv<bf16_t><<<g1, tw_, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
                                                      pl->cols8, n2, n4, n8, y2, y4, y8);
     SR_LAUNCH_CHECK();
     return SR_OK;

@@ -491,7 +491,7 @@ static int launch_rows_fwd(View x, int ups, bool shortcut, int B, int H, int PT,
         if (shortcut) {  // one half-length transform per source row
             constexpr int NS = N / 2, PS = pairs_for(NS);
             const size_t ldss = (size_t)NS * PS * sizeof(float2) + (size_t)NS * sizeof(float2);
-            SR_HIP(hipFuncSetAttribute((const void*)rows_fwd_up<T, NS, PS, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
+            SR_LDS_ATTR(ldss, rows_fwd_up<T, NS, PS, BLK>);
             rows_fwd_up<T, NS, PS, BLK><<<dim3(B * (H / 2), cdiv(PT, PS)), THREADS, ldss, st>>>(x, H, PT, im, pl->tw_w, pl->half[0], t1);
             SR_LAUNCH_CHECK();
             return SR_OK;
@@ -502,10 +502,10 @@ static int launch_rows_fwd(View x, int ups, bool shortcut, int B, int H, int PT,
     // kept columns of the widest mask inside the outer quarters: the last pass skips the middle half of its outputs
     const bool pz = pl->half[0] <= N / 4 && fwd_oz<N, true>() != 0;
     if (pz) {
-        SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P, BLK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_LDS_ATTR(lds, rows_fwd<T, N, P, BLK, true>);
         rows_fwd<T, N, P, BLK, true><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, im, pl->tw_w, pl->half[0], t1);
     } else {
-        SR_HIP(hipFuncSetAttribute((const void*)rows_fwd<T, N, P, BLK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_LDS_ATTR(lds, rows_fwd<T, N, P, BLK, false>);
         rows_fwd<T, N, P, BLK, false><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(x, ups, H, PT, im, pl->tw_w, pl->half[0], t1);
     }
     SR_LAUNCH_CHECK();
@@ -521,11 +521,11 @@ static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inte
     const bool pz = first_radix(N) == 8 && (zero_mask<N>(pl->half[0]) & 0x3c) == 0x3c && (zero_mask<N>(pl->half[1]) & 0x3c) == 0x3c &&
                     (zero_mask<N>(pl->half[2]) & 0x7e) == 0x7e;
     if (pz) {
-        SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P, BLK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_LDS_ATTR(lds, rows_inv<T, N, P, BLK, true>);
         rows_inv<T, N, P, BLK, true><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
                                                                             pl->half[1], pl->half[2], y2, y4, y8);
     } else {
-        SR_HIP(hipFuncSetAttribute((const void*)rows_inv<T, N, P, BLK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_LDS_ATTR(lds, rows_inv<T, N, P, BLK, false>);
         rows_inv<T, N, P, BLK, false><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
                                                                             pl->half[1], pl->half[2], y2, y4, y8);
     }
@@ -543,7 +543,7 @@ static int launch_cols(bool shortcut, int B, int W, int PT, int C, Inter im, con
     const dim3 grid(B * pl->n[0], cdiv(PT, P));
 #define SR_COLS(PZ_, UPS_)                                                                                                   \
     do {                                                                                                                     \
-        SR_HIP(hipFuncSetAttribute((const void*)cols<N, P, BLK, PZ_, UPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        SR_LDS_ATTR(lds, cols<N, P, BLK, PZ_, UPS_>); \
         cols<N, P, BLK, PZ_, UPS_><<<grid, THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1], pl->half[2],    \
                                                              pl->rowmask, t1, y2, y4, y8, pooled, pooled_ld, C);             \
     } while (0)

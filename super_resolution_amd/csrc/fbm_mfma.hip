@@ -832,7 +832,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     // fp16 range of the intermediates: an orthonormal coefficient can reach sqrt(W) (sqrt(H W)) times the largest
     // activation, so T and U are kept as T / 4, U / 4 and S as S / 64 (no overflow below |x| ~ 8000; the epilogues saturate)
     a1.scale = 0.25f;
-    SR_HIP(hipFuncSetAttribute((const void*)mf_analysis<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ana));
+    SR_LDS_ATTR(lds_ana, mf_analysis<true>);
     mf_analysis<true><<<grid_for(H, 2), THREADS, lds_ana, st>>>(a1);
     SR_LAUNCH_CHECK();
 
@@ -855,7 +855,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     a2.pooled = pooled;
     a2.pooled_ld = pooled_ld;
     a2.pool_scale = 4.0f / std::sqrt((float)H * (float)W);
-    SR_HIP(hipFuncSetAttribute((const void*)mf_analysis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ana));
+    SR_LDS_ATTR(lds_ana, mf_analysis<false>);
     mf_analysis<false><<<grid_for(jw, 2), THREADS, lds_ana, st>>>(a2);
     SR_LAUNCH_CHECK();
 
@@ -880,7 +880,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     s3.CG = CG;
     s3.basis = (const h16*)pl->mf_ph;
     s3.nks_tab = pl->mf_ld_ph / 16;
-    SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_syn));
+    SR_LDS_ATTR(lds_syn, mf_synthesis<true>);
     mf_synthesis<true><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
     SR_LAUNCH_CHECK();
 
@@ -904,12 +904,12 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         for (int k = 0; k < 3; ++k) s4.ksm[k] = (pl->mf_nw[k] / 2 + 15) / 16;  // k-steps per half (cos / sin)
         s4.basis = (const h16*)pl->mf_qwf;
         s4.nks_tab = 16;
-        SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis_wf, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_B));
+        SR_LDS_ATTR(2 * IMG_B, mf_synthesis_wf);
         mf_synthesis_wf<<<grid_for(H, 4), THREADS, 2 * IMG_B, st>>>(s4);
     } else {
         s4.basis = (const h16*)pl->mf_qw;
         s4.nks_tab = pl->mf_ld_qw / 16;
-        SR_HIP(hipFuncSetAttribute((const void*)mf_synthesis<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_syn));
+        SR_LDS_ATTR(lds_syn, mf_synthesis<false>);
         mf_synthesis<false><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
     }
     SR_LAUNCH_CHECK();

@@ -528,7 +528,7 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
     const dim3 grid((unsigned)std::min<long>(nblk, per_cu * ncu));
 #define SR_GATES_ACC(NC)                                                                                                 \
     case NC:                                                                                                             \
-        SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_acc_mfma<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        SR_LDS_ATTR(lds, fbm_gates_acc_mfma<NC>); \
         fbm_gates_acc_mfma<NC><<<grid, 256, lds, st>>>(seg, B, H, W, cl);                                                  \
         break;
     switch (cl.n) {
@@ -554,7 +554,7 @@ int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_
                      hipStream_t st) {
     if (dtype == SR_BF16 && !g_force_generic_gates && gates_mfma_eligible(in)) {
         const size_t lds = (size_t)GNT * 32 * GTROW * sizeof(float) + 32ul * (in.ctot * 2 + 16);
-        SR_HIP(hipFuncSetAttribute((const void*)fbm_gates_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SR_LDS_ATTR(lds, fbm_gates_mfma);
         const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
         if (nblk >= (1L << 31)) return SR_ERR_ARG;
         static int ncu = 0;
