@@ -253,9 +253,28 @@ __device__ float2* fft_run(float2* bufA, float2* bufB, float2* bufC, bool keep_i
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
+// both channels of a complex signal in one access (channel-contiguous layouts with an even channel count)
+template <typename T>
+struct PairIO;
+template <>
+struct PairIO<float> {
+    static __device__ __forceinline__ float2 ld(const float* p) { return *(const float2*)p; }
+    static __device__ __forceinline__ void st(float* p, float2 v) { *(float2*)p = v; }
+};
+template <>
+struct PairIO<bf16_t> {
+    static __device__ __forceinline__ float2 ld(const bf16_t* p) {
+        const uint32_t u = *(const uint32_t*)p;
+        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, float2 v) {
+        *(uint32_t*)p = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    }
+};
+
 // ---- kernel 1: forward FFT along W ---------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int H, int W, int C, int PT, int P, Radix rx,
+__global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, int H, int W, int C, int PT, int P, Radix rx,
                                                     const float2* __restrict__ tw, const int* __restrict__ cols, int n2,
                                                     float2* __restrict__ t1) {
     float2* bufA = (float2*)smem;
@@ -271,8 +290,12 @@ __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int H, int
         const int c = 2 * (p0 + p);
         const long pix = (long)(h >> ups) * Ws + (w >> ups);
         float2 v = make_float2(0.f, 0.f);
-        if (c < C) v.x = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c));
-        if (c + 1 < C) v.y = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c + 1));
+        if (pair) {
+            if (c < C) v = PairIO<T>::ld((const T*)x.p + voff(x, b, pix, c));
+        } else {
+            if (c < C) v.x = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c));
+            if (c + 1 < C) v.y = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c + 1));
+        }
         bufA[it] = v;
     }
     __syncthreads();
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
 
 // ---- kernel 3: inverse FFT along W, write the three low-pass tensors ------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, int H, int W, int C, int PT, int P,
+__global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, int pair, int H, int W, int C, int PT, int P,
                                                     Radix rx, const float2* __restrict__ tw,
                                                     const int* __restrict__ cols2, const int* __restrict__ cols4,
                                                     const int* __restrict__ cols8, int n2, int n4, int n8,
@@ -368,8 +391,12 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
             const int c = 2 * (p0 + p);
             const float2 v = res[it];
             const long pix = (long)h * W + w;
-            if (c < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c), v.x * norm);
-            if (c + 1 < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c + 1), v.y * norm);
+            if (pair) {
+                if (c < C) PairIO<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c), make_float2(v.x * norm, v.y * norm));
+            } else {
+                if (c < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c), v.x * norm);
+                if (c + 1 < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c + 1), v.y * norm);
+            }
         }
         __syncthreads();
     }
@@ -421,6 +448,8 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
         return resident >= 4 ? 256 : (resident >= 2 ? 512 : 1024);
     };
     const int tw_ = threads_for(lds_w), th_ = threads_for(lds_h);
+    const int pair_in = C % 2 == 0 && view_vec_ok(x, 2);
+    const int pair_out = C % 2 == 0 && view_vec_ok(l2, 2) && view_vec_ok(l4, 2) && view_vec_ok(l8, 2);
     if (dtype == SR_F32) {
         SR_LDS_ATTR(lds_w, fbm_rows_fwd<float>);
         SR_LDS_ATTR(lds_w, fbm_rows_inv<float>);
@@ -430,18 +459,18 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     }
     SR_LDS_ATTR(lds_h, fbm_cols);
     if (dtype == SR_F32)
-        fbm_rows_fwd<float><<<g1, tw_, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+        fbm_rows_fwd<float><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
     else
-        fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+        fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
     SR_LAUNCH_CHECK();
     fbm_cols<<<g2, th_, lds_h, st>>>(H, W, PT, Ph, rh, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
                                      pooled, pooled_ld, C);
     SR_LAUNCH_CHECK();
     if (dtype == SR_F32)
-        fbm_rows_inv<float><<<g1, tw_, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+        fbm_rows_inv<float><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
                                                     pl->cols8, n2, n4, n8, y2, y4, y8);
     else
-        fbm_rows_inv<bf16_t><<<g1, tw_, lds_w, st>>>(l2, l4, l8, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+        fbm_rows_inv<bf16_t><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
                                                      pl->cols8, n2, n4, n8, y2, y4, y8);
     SR_LAUNCH_CHECK();
     return SR_OK;
