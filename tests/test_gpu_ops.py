@@ -132,7 +132,9 @@ def _run_lowpass(L, lib, x, dt, ups):
 
 
 @pytest.mark.parametrize('shape', [(2, 6, 12, 12), (1, 5, 33, 35), (2, 32, 40, 48), (1, 64, 64, 64), (1, 8, 130, 77),
-                                   (1, 4, 58, 36), (1, 2, 128, 256)])
+                                   (1, 4, 58, 36), (1, 2, 128, 256),
+                                   # long non-power-of-two sides: 512- and 1024-thread blocks, radix 3 / 5 / 7 butterflies
+                                   (1, 3, 1200, 36), (1, 4, 24, 1920), (1, 2, 2100, 20)])
 def test_fbm_lowpass_fp32(L, shape):
     x = torch.from_numpy(gp.signed_input(shape, 11))
     bands, pooled = run_lowpass(L, x, torch.float32)
