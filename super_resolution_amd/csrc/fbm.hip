@@ -277,6 +277,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, int H, int W, int C, int PT, int P, Radix rx,
                                                     const float2* __restrict__ tw, const int* __restrict__ cols, int n2,
                                                     float2* __restrict__ t1) {
+    const int lp = 31 - __clz(P);  // P is a power of two (pairs_per_group)
     float2* bufA = (float2*)smem;
     float2* bufB = bufA + W * P;
     float2* twl = bufB + W * P;  // twiddles staged in LDS: every butterfly term reads one
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, 
     const int Ws = W >> ups;
     #pragma unroll 8
     for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
-        const int p = it % P, w = it / P;
+        const int p = it & (P - 1), w = it >> lp;
         const int c = 2 * (p0 + p);
         const long pix = (long)(h >> ups) * Ws + (w >> ups);
         float2 v = make_float2(0.f, 0.f);
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, 
     // t1[b][idx][h][PT]
     #pragma unroll 8
     for (int it = threadIdx.x; it < n2 * P; it += blockDim.x) {
-        const int p = it % P, idx = it / P;
+        const int p = it & (P - 1), idx = it >> lp;
         if (p0 + p < PT) t1[(((long)b * n2 + idx) * H + h) * PT + p0 + p] = res[cols[idx] * P + p];
     }
 }
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
                                                 float2* __restrict__ y2, float2* __restrict__ y4,
                                                 float2* __restrict__ y8, float* __restrict__ pooled, int pooled_ld,
                                                 int C) {
+    const int lp = 31 - __clz(P);  // P is a power of two
     float2* buf0 = (float2*)smem;
     float2* buf1 = buf0 + H * P;
     float2* buf2 = buf1 + H * P;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
     const float2* col = t1 + ((long)b * n2 + idx) * H * PT;
     #pragma unroll 8
     for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
-        const int p = it % P, h = it / P;
+        const int p = it & (P - 1), h = it >> lp;
         buf0[it] = (p0 + p < PT) ? col[(long)h * PT + p0 + p] : make_float2(0.f, 0.f);
     }
     __syncthreads();
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
         float2* y = ys[k];
         #pragma unroll 8
         for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
-            const int p = it % P, h = it / P;
+            const int p = it & (P - 1), h = it >> lp;
             if (p0 + p < PT) y[(((long)b * H + h) * nk[k] + kidx[k]) * PT + p0 + p] = res[it];
         }
         __syncthreads();
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
                                                     const int* __restrict__ cols8, int n2, int n4, int n8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
                                                     const float2* __restrict__ y8) {
+    const int lp = 31 - __clz(P);  // P is a power of two
     float2* bufA = (float2*)smem;
     float2* bufB = bufA + W * P;
     float2* twl = bufB + W * P;
@@ -380,14 +383,14 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
         const float2* yr = ys[k] + ((long)b * H + h) * nk[k] * PT;
         #pragma unroll 8
         for (int it = threadIdx.x; it < nk[k] * P; it += blockDim.x) {
-            const int p = it % P, i = it / P;
+            const int p = it & (P - 1), i = it >> lp;
             if (p0 + p < PT) bufA[ck[k][i] * P + p] = yr[(long)i * PT + p0 + p];
         }
         __syncthreads();
         const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
         #pragma unroll 8
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
-            const int p = it % P, w = it / P;
+            const int p = it & (P - 1), w = it >> lp;
             const int c = 2 * (p0 + p);
             const float2 v = res[it];
             const long pix = (long)h * W + w;
