@@ -190,13 +190,15 @@ struct Run {
         if (lp.active) {
             float* gates = (float*)(ws + L.gates);
             // pooled means are ready (low-pass kernels above): fork the weight generation, run the gates meanwhile
-            hipStream_t wgs = net->side ? net->side : st;
-            if (net->side && (hipEventRecord(net->ev_fork, st) != hipSuccess || hipStreamWaitEvent(net->side, net->ev_fork, 0) != hipSuccess)) { rc = SR_ERR_HIP; return; }
+            // (small inputs stay on one stream: a fork/join pair costs ~40 us of host time, more than the overlap returns)
+            const bool fork = net->side && (long)B * H * W >= 512L * 512;
+            hipStream_t wgs = fork ? net->side : st;
+            if (fork && (hipEventRecord(net->ev_fork, st) != hipSuccess || hipStreamWaitEvent(net->side, net->ev_fork, 0) != hipSuccess)) { rc = SR_ERR_HIP; return; }
             prof_begin(G_WGEN, wgs);
             rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn, wgs);
             prof_end(wgs);
             if (rc != SR_OK) return;
-            if (net->side && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
+            if (fork && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(G_GATES);
             bool done = false;
             if (rdb_k >= 0 && dtype == SR_BF16 && nseg == rdb_k + 1) {
@@ -224,7 +226,7 @@ struct Run {
             if (!done && rc == SR_OK) rc = fbm_gates_launch(dtype, B, Hc, Wc, c, lp, gates, st);
             prof_end();
             if (rc != SR_OK) return;
-            if (net->side && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
+            if (fork && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(G_CONV);
             rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, lp.cout, ep, out, st);
             prof_end();
