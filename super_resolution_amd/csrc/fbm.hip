@@ -234,8 +234,10 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
 
 // Runs all passes; returns the buffer that holds the result.  bufA holds the input.  When
 // `keep_input` is set the input buffer is never written (needs a third buffer bufC).
+// (forced inline: as an out-of-line function -- which hipcc chose once the pass switch grew by four more radices -- the
+// kernels took a stack, passed the Radix kernel argument by reference and faulted in the 33-point test)
 template <bool INV>
-__device__ float2* fft_run(float2* bufA, float2* bufB, float2* bufC, bool keep_input, int N, const Radix& rx, int P,
+__device__ __forceinline__ float2* fft_run(float2* bufA, float2* bufB, float2* bufC, bool keep_input, int N, const Radix& rx, int P,
                            const float2* tw, const float* premul) {
     float2* src = bufA;
     float2* dst = bufB;
