@@ -493,7 +493,8 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
     // direct form: 64-channel segments (278 vs 405 us with five consumers at batch 16 of 512 x 512); at 32 channels the
     // T-image kernel below is as fast or faster (211 vs 246 us with four consumers), SR_AMD_GATES_DIRECT=1 forces it
     static const bool direct32 = getenv("SR_AMD_GATES_DIRECT") && atoi(getenv("SR_AMD_GATES_DIRECT")) == 1;
-    if ((seg.C == 64 || (seg.C == 32 && direct32)) && !g_gates_no_direct) {
+    // (up to five consumers, a dense block's worth: the variants for more would spill at 64 channels)
+    if ((seg.C == 64 || (seg.C == 32 && direct32)) && cl.n <= 5 && !g_gates_no_direct) {
         const int ck = seg.C / 16;
         const size_t ldsd = (size_t)GSLOTS * (seg.C * 2 + 16) + (size_t)4 * cl.n * (9 * seg.C * 2 + 16);
         static int resident[SR_MAX_GATE_CONSUMERS + 1][2];  // persistent grid = resident workgroups
@@ -515,8 +516,7 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
         else SR_GATES_DIRECT_V(NC, 4);                                                                                   \
         break;
         switch (cl.n) {
-            SR_GATES_DIRECT(1) SR_GATES_DIRECT(2) SR_GATES_DIRECT(3) SR_GATES_DIRECT(4) SR_GATES_DIRECT(5) SR_GATES_DIRECT(6)
-            SR_GATES_DIRECT(7) SR_GATES_DIRECT(8)
+            SR_GATES_DIRECT(1) SR_GATES_DIRECT(2) SR_GATES_DIRECT(3) SR_GATES_DIRECT(4) SR_GATES_DIRECT(5)
         }
 #undef SR_GATES_DIRECT
 #undef SR_GATES_DIRECT_V
