@@ -208,7 +208,9 @@ struct Logit3 {
     float x, y, z;
 };
 
-template <int NC>
+// KMAX = k-steps (16 channels each) this instance can hold: 2 for segments of up to 32 channels (half the fragment loads and
+// registers of the general one), 4 for up to 64
+template <int NC, int KMAX>
 __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H, int W, GateConsList cl) {
     extern __shared__ __attribute__((aligned(16))) char glds[];
     float* T = (float*)glds;                                  // [GNT*32][27]
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
         const int tile = lin % tiles, b = lin / tiles;
         const int h0 = (tile / tilesx) * GMH, w0p = (tile % tilesx) * GMW;
         // this wave's N-tiles: wave, wave + 4, wave + 8 (< GNT = 11); all their fragments are fetched once
-        g_short8 frag[3][4];
+        g_short8 frag[3][KMAX];
         bool ok[3];
         int slot[3];
 #pragma unroll
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
             ok[u] = nt < GNT && slot[u] < GSLOTS && h >= 0 && h < H && w >= 0 && w < W;
             const long ps = (long)min(max(h, 0), H - 1) * W + min(max(w, 0), W - 1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < KMAX; ++t)
                 frag[u][t] = *(const g_short8*)((const bf16_t*)seg.p + voff(seg, b, ps, min(16 * t, C - 16) + hk * 8));
         }
         const int ty = tid / GMW, tx = tid % GMW;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void fbm_gates_acc_mfma(View seg, int B, int H
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < KMAX; ++t) {
                     if (t >= nks) break;
                     const g_short8 afrag = *(const g_short8*)(A + (ci * 32 + r) * astride + (16 * t + hk * 8) * 2);
                     const g_short8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -528,8 +530,13 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
     const dim3 grid((unsigned)std::min<long>(nblk, per_cu * ncu));
 #define SR_GATES_ACC(NC)                                                                                                 \
     case NC:                                                                                                             \
-        SR_LDS_ATTR(lds, fbm_gates_acc_mfma<NC>); \
-        fbm_gates_acc_mfma<NC><<<grid, 256, lds, st>>>(seg, B, H, W, cl);                                                  \
+        if (seg.C <= 32) {                                                                                               \
+            SR_LDS_ATTR(lds, fbm_gates_acc_mfma<NC, 2>);                                                                 \
+            fbm_gates_acc_mfma<NC, 2><<<grid, 256, lds, st>>>(seg, B, H, W, cl);                                         \
+        } else {                                                                                                         \
+            SR_LDS_ATTR(lds, fbm_gates_acc_mfma<NC, 4>);                                                                 \
+            fbm_gates_acc_mfma<NC, 4><<<grid, 256, lds, st>>>(seg, B, H, W, cl);                                         \
+        }                                                                                                                \
         break;
     switch (cl.n) {
         SR_GATES_ACC(1) SR_GATES_ACC(2) SR_GATES_ACC(3) SR_GATES_ACC(4) SR_GATES_ACC(5) SR_GATES_ACC(6) SR_GATES_ACC(7) SR_GATES_ACC(8)
