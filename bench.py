@@ -1,25 +1,36 @@
 #!/usr/bin/env python
-"""bench.py -- output Mpix/s of RRDBNet-FDConv x4 inference (BASELINE.json configs[1]) on N MI355X.
+"""bench.py -- output Mpix/s of RRDBNet-FDConv x4 inference on N MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 5 --warmup 2                    # BASELINE.json configs[1] (the metric's config)
+    python bench.py --config tiled --steps 1 --warmup 1              # BASELINE.json configs[2]: 4096^2 tiled image
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W [--config tiled]
 
-A step = one forward of RRDBNet(1,1,64,23,32) with every conv swapped for FDConv, on a synthetic batch of
-16 grayscale 512x512 images that is already resident in HBM, computed in bf16 (MFMA) through libsr_amd.
-The path shards by batch with no exchange step, so every rank runs the same per-GPU batch ("weak").
+--config batch (default): a step = one forward of RRDBNet(1,1,64,23,32) with every conv swapped for FDConv on a
+synthetic batch of 16 grayscale 512x512 images already resident in HBM, bf16 (MFMA) through libsr_amd.  The path
+shards by batch with no exchange step, so every rank runs the same per-GPU batch ("weak").
+--config tiled: a step = RealESRGANer(tile=512, tile_pad=10, pre_pad=0, half=True, shard_tiles=True).tile_process()
++ post_process() of one 4096x4096 RGB image that pre_process has already placed in HBM, RRDBNet-FDConv(3,3,64,23,32);
+the 64 tiles are dealt area-sorted round-robin over the N ranks and rank 0 gathers the cores point to point
+("strong": the image is fixed).  The host-to-host enhance() time and the non-parallel share are reported beside it.
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
-  roofline     : the conv kernels (the dominant launch group; HBM-bound on FDConv layers), measured live with HIP
-                 events recorded by the executor on the launch stream around every conv launch of the timed steps;
+  roofline     : the conv kernels on the MFMA roof as SURVEY 8(d) prescribes (conv FLOPs / conv kernel time / 2.5
+                 PFLOP/s), measured live with HIP events recorded by the executor on the launch stream around every
+                 conv launch of the timed steps; `hbm` = the same kernels against the HBM roof on STRICT algorithmic
+                 bytes (every conv input once, output once, residual operands once); `groups` = low-pass, gates and
+                 head convs against the HBM roof on their strict bytes;
   cpu_baseline : the CPU oracle (torch fp32 restatement pinned by the golden fixtures) timed on this host on a
                  bounded sample of the same workload.
 """
 import argparse
+import glob
 import json
 import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,47 +40,52 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 NUM_FEAT, NUM_BLOCK, NUM_GROW = 64, 23, 32
+ES = 2                          # bytes per activation element (bf16)
 
 
-def conv_macs_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_GROW):
-    """algorithmic conv MACs of RRDBNet x4 per LR pixel (17,905,056 for 1-channel I/O)."""
+def conv_macs_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_GROW, head_only=False):
+    """algorithmic conv MACs of RRDBNet x4 per LR pixel."""
     rdb = 9 * (sum((nf + k * gc) * gc for k in range(4)) + (nf + 4 * gc) * nf)
-    return 9 * cin0 * nf + 3 * nb * rdb + 9 * nf * nf * (1 + 4 + 16 + 16) + 16 * 9 * nf * cout_last
+    head = 9 * nf * nf * (4 + 16 + 16) + 16 * 9 * nf * cout_last   # conv_up1, conv_up2, conv_hr, conv_last
+    if head_only:
+        return head
+    return 9 * cin0 * nf + 3 * nb * rdb + 9 * nf * nf + head
 
 
-def conv_bytes_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_GROW, es=2):
-    """SURVEY 8(d) / DESIGN.md 4: algorithmic HBM bytes of all conv launches of one forward, per LR pixel per sample.
-
-    An FDConv conv must read its input and the three low-pass planes of it (4 x cin elements per input pixel) plus
-    the three fp32 gates (12 B per input pixel), and write cout elements per output pixel; residual operands add
-    cout elements each; thin layers (conv_first / conv_last, min(c) <= 16) are plain convs.  Per-sample weights
-    are a few hundred KB per launch and are not counted.  `es` = bytes per activation element (2: bf16).
-    """
-    def fd(cin, cout, in_px, out_px, nres=0):
-        return in_px * (4 * cin * es + 12) + out_px * cout * es * (1 + nres)
-    tot = 1 * (cin0 * es) + 1 * nf * es                       # conv_first (plain)
+def strict_bytes_per_lr_pixel(cin0, cout_last, nf=NUM_FEAT, nb=NUM_BLOCK, gc=NUM_GROW, es=ES):
+    """Strict algorithmic HBM bytes per LR pixel per sample of each kernel group (read every input once,
+    write every output once).
+      conv    : trunk convs (conv_first, 69 RDB x 5, conv_body): cin in + cout out + cout per residual operand
+      head    : conv_up1 (reads LR, writes 2x), conv_up2 (2x -> 4x), conv_hr, conv_last
+      lowpass : per produced tensor that feeds an FDConv layer: read x once, write three planes (8 B / px / channel in
+                bf16); 192 channels per RDB + conv_body's input; lowpass_hr: the inputs of conv_up1 / conv_up2 / conv_hr
+                (read at the source resolution, written at the conv's resolution)
+      gates   : per RDB read the 192 produced channels once and write 5 gate records (float4); + conv_body and the three
+                FDConv head layers (read cin, write one record per pixel of their resolution)"""
+    rec = 16
+    conv = cin0 * es + nf * es
     for blk in range(3 * nb):
         for k in range(4):
-            tot += fd(nf + k * gc, gc, 1, 1)
-        tot += fd(nf + 4 * gc, nf, 1, 1, nres=2 if blk % 3 == 2 else 1)
-    tot += fd(nf, nf, 1, 1, nres=1)                           # conv_body + trunk residual
-    tot += fd(nf, nf, 1, 4)                                   # conv_up1 reads LR, writes 2x
-    tot += fd(nf, nf, 4, 16)                                  # conv_up2 reads 2x, writes 4x
-    tot += fd(nf, nf, 16, 16)                                 # conv_hr
-    tot += 16 * nf * es + 16 * cout_last * es                 # conv_last (plain)
-    return tot
+            conv += (nf + k * gc) * es + gc * es
+        conv += (nf + 4 * gc) * es + nf * es * (1 + (2 if blk % 3 == 2 else 1))
+    conv += nf * es + nf * es * 2
+    head = (nf * es + 4 * nf * es) + (4 * nf * es + 16 * nf * es) + (16 * nf * es + 16 * nf * es) + (16 * nf * es + 16 * cout_last * es)
+    lowpass = (3 * nb * (nf + 4 * gc) + nf) * 4 * es
+    lowpass_hr = (nf * es + 4 * 3 * nf * es) + (4 * nf * es + 16 * 3 * nf * es) + (16 * nf * es + 16 * 3 * nf * es)
+    gates = 3 * nb * ((nf + 4 * gc) * es + 5 * rec) + (nf * es + rec) + (nf * es + 4 * rec) + (4 * nf * es + 16 * rec) + (16 * nf * es + 16 * rec)
+    return {'conv': conv, 'head': head, 'lowpass': lowpass, 'lowpass_hr': lowpass_hr, 'gates': gates}
 
 
-def measured_conv_traffic():
-    """HBM bytes per conv launch from the committed PMC passes of this same command (profiles/*_hbm_traffic.json:
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; counters cannot be read in-process)."""
-    import glob
+def measured_traffic():
+    """HBM bytes per launch and kernel group from the committed PMC passes of this same command (profiles/
+    *_hbm_traffic.json, newest round: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE;
+    counters cannot be read in-process)."""
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))
     if not files:
-        return None, None
+        return {}, None
     with open(files[-1]) as f:
         d = json.load(f)
-    return d['per_launch']['conv']['hbm_gb_per_launch_corrected'] * 1e9, os.path.relpath(files[-1], ROOT)
+    return {k: v['hbm_gb_per_launch_corrected'] * 1e9 for k, v in d['per_launch'].items()}, os.path.relpath(files[-1], ROOT)
 
 
 def synthetic_batch(B, H, W, device, seed=1234):
@@ -84,28 +100,198 @@ def synthetic_batch(B, H, W, device, seed=1234):
     return x.to(device)
 
 
-def build_model(device, seed=1234):
+def build_model(device, ch=1, seed=1234):
     import golden_params as gp
     from super_resolution_amd import RRDBNet, replace_conv_with_fdconv
-    net = replace_conv_with_fdconv(RRDBNet(1, 1, 4, NUM_FEAT, NUM_BLOCK, NUM_GROW))
-    sd = {k: torch.from_numpy(v) for k, v in gp.rrdbnet_state(1, 1, NUM_FEAT, NUM_BLOCK, NUM_GROW, seed=seed).items()}
+    net = replace_conv_with_fdconv(RRDBNet(ch, ch, 4, NUM_FEAT, NUM_BLOCK, NUM_GROW))
+    sd = {k: torch.from_numpy(v) for k, v in gp.rrdbnet_state(ch, ch, NUM_FEAT, NUM_BLOCK, NUM_GROW, seed=seed).items()}
     net.load_state_dict(sd, strict=True)
     return net.eval().to(device), sd
 
 
-def cpu_baseline(sd, sample_hw):
+def cpu_baseline(sd, sample_hw, ch=1):
     """Oracle forward on the host cores on a bounded sample; returns the dict for the JSON line."""
     from oracle.rrdbnet_ref import rrdbnet_forward
     threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or torch.get_num_threads()
     torch.set_num_threads(threads)
     x = synthetic_batch(1, sample_hw, sample_hw, 'cpu')
+    if ch > 1:
+        x = x.expand(1, ch, sample_hw, sample_hw).contiguous()
     t0 = time.perf_counter()
     with torch.no_grad():
         y = rrdbnet_forward(sd, x)
     dt = time.perf_counter() - t0
     return {'value': y.shape[-1] * y.shape[-2] / 1e6 / dt, 'unit': 'output Mpix/s', 'cores': threads, 'kind': 'port',
-            'sample': 'one forward of the same 23-block RRDBNet-FDConv on 1x1x%dx%d (fp32 torch oracle, %.1f s), '
-                      'no extrapolation' % (sample_hw, sample_hw, dt)}
+            'sample': 'one forward of the same 23-block RRDBNet-FDConv on 1x%dx%dx%d (fp32 torch oracle, %.1f s), '
+                      'no extrapolation' % (ch, sample_hw, sample_hw, dt)}
+
+
+def roofline_fields(prof, prof_all, steps, lr_px_step, ch):
+    """roofline object from the executor's event timings.  prof: conv groups over the timed steps; prof_all: every
+    group over one extra untimed step; lr_px_step: LR pixels x samples one step pushes through the network."""
+    conv_ms = prof['conv'][0] + prof['head'][0]
+    conv_n = prof['conv'][1] + prof['head'][1]
+    conv_s_step = conv_ms / 1e3 / steps
+    flops_step = 2.0 * conv_macs_per_lr_pixel(ch, ch) * lr_px_step
+    tflops = flops_step / conv_s_step / 1e12
+    strict = strict_bytes_per_lr_pixel(ch, ch)
+    traffic, traffic_src = measured_traffic()
+    n_step = max(conv_n // steps, 1)
+    conv_strict_gb = (strict['conv'] + strict['head']) * lr_px_step / 1e9
+    groups = {}
+    for g, keys in (('conv_trunk', ('conv',)), ('head', ('head',)), ('lowpass', ('lowpass',)), ('lowpass_hr', ('lowpass_hr',)),
+                    ('gates', ('gates',))):
+        ms = sum(prof_all[k][0] for k in keys)
+        gb = sum(strict[k] for k in keys) * lr_px_step / 1e9
+        if ms > 0:
+            groups[g] = {'ms_per_step': ms, 'launches': sum(prof_all[k][1] for k in keys), 'algorithmic_gb_per_step': gb,
+                         'achieved_gbs': gb / (ms / 1e3), 'frac_of_hbm_peak': gb / (ms / 1e3) / HBM_PEAK_GBS}
+    head_ms = prof_all['head'][0]
+    if head_ms > 0:
+        groups['head']['tflops'] = 2.0 * conv_macs_per_lr_pixel(ch, ch, head_only=True) * lr_px_step / (head_ms / 1e3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'conv3x3_mfma_bf16 (all %d conv launches of a step)' % n_step,
+            'achieved': tflops, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / BF16_MFMA_PEAK_TFLOPS,
+            'algorithmic_tflop_per_step': flops_step / 1e12, 'avg_launch_ms': conv_ms / max(conv_n, 1),
+            'traffic': traffic.get('conv'), 'traffic_unit': 'HBM bytes per average conv launch (PMC, %s)' % traffic_src,
+            'hbm': {'achieved': conv_strict_gb / conv_s_step, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': conv_strict_gb / conv_s_step / HBM_PEAK_GBS,
+                    'algorithmic_gb_per_launch': conv_strict_gb / n_step,
+                    'note': 'strict bytes: every conv input once + output once + residual operands; the FDConv operand '
+                            'as implemented streams x and three low-pass planes per consumer (4 x cin), see DESIGN.md'},
+            'groups': groups, 'traffic_per_launch_all_groups': traffic}
+
+
+def run_batch(args, world, rank, dev, dist):
+    net, sd = build_model(dev, 1)
+    B, H, W = args.batch, args.size, args.size
+    x = synthetic_batch(B, H, W, dev, seed=1234 + rank).to(torch.bfloat16)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            y = net(x)
+        sync()
+        net.profile(2)  # HIP events around the conv launches only: 11 ms/step less than with every group
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = net(x)
+        sync()
+        elapsed = time.perf_counter() - t0
+        prof = net.profile_read()
+        net.profile(1)  # per-group breakdown from one extra, untimed step
+        net(x)
+        sync()
+        prof_all = net.profile_read()
+    net.profile(False)
+    finite = bool(torch.isfinite(y.float()).all())
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+    out_mpix = world * B * (4 * H) * (4 * W) / 1e6
+    res = {
+        'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
+        'value': out_mpix / (elapsed / args.steps), 'unit': 'output Mpix/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': max(args.warmup, 1), 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'RRDBNet-FDConv(1,1,64,23,32) x4 inference, batch %d of %dx%d synthetic grayscale per GPU, '
+                               'bf16 (BASELINE.json configs[1])' % (B, H, W),
+                   'global_batch': world * B, 'parallelism': 'batch-sharded replicas x%d, no exchange' % world,
+                   'output_finite': finite},
+        'roofline': roofline_fields(prof, prof_all, args.steps, float(B) * H * W, 1),
+        'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},
+        'kernel_launches_per_step': {k: v[1] for k, v in prof_all.items()},
+        'kernel_ms_source': 'one extra untimed step with events around every kernel group; the conv events of the roofline are in the timed steps',
+    }
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(sd, args.cpu_sample, 1)
+    return res
+
+
+def run_tiled(args, world, rank, dev, dist):
+    from super_resolution_amd import RealESRGANer
+    net, sd = build_model(dev, 3)
+    side = args.image
+    img = (np.random.default_rng(1234).random((side, side, 3)) * 255).astype(np.uint8)
+    r = RealESRGANer(scale=4, model_path=None, model=net, tile=args.tile, tile_pad=args.tile_pad, pre_pad=0, half=True,
+                     device=dev, shard_tiles=True, tile_batch=args.tile_batch)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # the image is placed in HBM before the timed region (pre_process: host -> device, float conversion)
+    t0 = time.perf_counter()
+    r.pre_process(img[:, :, ::-1].astype(np.float32) / 255.0)
+    torch.cuda.synchronize(dev)
+    t_pre = time.perf_counter() - t0
+    wins = r.tile_windows()
+    mine = r.shard_of(wins, rank, world)
+    lr_px_rank = float(sum((wins[i][0][1] - wins[i][0][0]) * (wins[i][0][3] - wins[i][0][2]) for i in mine))
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            r.tile_process()
+            r.post_process()
+        sync()
+        net.profile(2)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.tile_process()
+            out = r.post_process()
+        sync()
+        elapsed = time.perf_counter() - t0
+        prof = net.profile_read()
+        net.profile(1)
+        r.tile_process()
+        sync()
+        prof_all = net.profile_read()
+        net.profile(False)
+        # whole enhance(), host image in -> host image out (PCIe, uint8 conversion and colour handling included)
+        sync()
+        t0 = time.perf_counter()
+        full, _mode = r.enhance(img)
+        sync()
+        t_enh = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+    out_mpix = (4 * side) * (4 * side) / 1e6
+    step_s = elapsed / args.steps
+    # event timings cover the last batch shape's executor only if the shapes differ -- the profile is per _NetState and
+    # accumulates over all forwards between profile() and profile_read(), which is what we want here
+    kernel_ms = sum(v[0] for v in prof_all.values())
+    res = {
+        'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
+        'value': out_mpix / step_s, 'unit': 'output Mpix/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': max(args.warmup, 1), 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'RealESRGANer(tile=%d, tile_pad=%d, pre_pad=0, half=True) x4 on one %dx%d synthetic RGB image, '
+                               'RRDBNet-FDConv(3,3,64,23,32), bf16 (BASELINE.json configs[2])' % (args.tile, args.tile_pad, side, side),
+                   'tiles': len(wins), 'tile_batch': args.tile_batch,
+                   'parallelism': '%d tiles area-sorted round-robin over %d rank(s), p2p gather of the cores to rank 0, no collective' % (len(wins), world),
+                   'timed_region': 'tile_process() + post_process() with the padded image resident in HBM; max over ranks incl. the gather',
+                   'enhance_host_to_host_s': t_enh, 'enhance_host_to_host_out_mpix_s': out_mpix / t_enh,
+                   'pre_process_s': t_pre,
+                   'non_parallel_share': {'note': 'rank 0, fraction of the timed step that is not network kernels of its own tiles '
+                                                  '(paste, gather, host launches not overlapped)',
+                                          'value': max(0.0, 1.0 - kernel_ms / 1e3 / step_s) if world == 1 else None,
+                                          'enhance_minus_timed_s': t_enh - step_s},
+                   'output_ok': bool(out is None or torch.isfinite(out.float()).all()) and (full is None or full.shape == (4 * side, 4 * side, 3))},
+        'roofline': roofline_fields(prof, prof_all, args.steps, lr_px_rank, 3),
+        'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},
+        'kernel_launches_per_step': {k: v[1] for k, v in prof_all.items()},
+    }
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(sd, args.cpu_sample, 3)
+    return res
 
 
 def main():
@@ -113,8 +299,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', choices=('batch', 'tiled'), default='batch')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')
+    ap.add_argument('--tile', type=int, default=512)
+    ap.add_argument('--tile-pad', type=int, default=10)
+    ap.add_argument('--tile-batch', type=int, default=8)
     ap.add_argument('--cpu-sample', type=int, default=208, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
     args = ap.parse_args()
@@ -134,80 +325,8 @@ def main():
     if world > 1:
         dist.barrier()
 
-    net, sd = build_model(dev)
-    B, H, W = args.batch, args.size, args.size
-    x = synthetic_batch(B, H, W, dev, seed=1234 + rank).to(torch.bfloat16)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            y = net(x)
-        sync()
-        net.profile(2)  # HIP events around the conv launches only (the roofline kernel): 11 ms/step less than all groups
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = net(x)
-        sync()
-        elapsed = time.perf_counter() - t0
-        prof = net.profile_read()
-        # per-group breakdown from one extra, untimed step with events around every kernel group
-        net.profile(1)
-        net(x)
-        sync()
-        prof_all = net.profile_read()
-    net.profile(False)
-    finite = bool(torch.isfinite(y.float()).all())
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax)
-
-    out_mpix = world * B * (4 * H) * (4 * W) / 1e6
-    ms_step = elapsed / args.steps * 1e3
-    conv_ms, conv_n = prof['conv']
-    conv_flops_step = 2.0 * conv_macs_per_lr_pixel(1, 1) * B * H * W
-    conv_s_step = conv_ms / 1e3 / args.steps
-    tflops = conv_flops_step / conv_s_step / 1e12
-    conv_bytes_step = float(conv_bytes_per_lr_pixel(1, 1)) * B * H * W
-    gbs = conv_bytes_step / conv_s_step / 1e9
-    traffic, traffic_src = measured_conv_traffic()
-    res = {
-        'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
-        'value': out_mpix / (elapsed / args.steps),
-        'unit': 'output Mpix/s',
-        'n_gpus': world,
-        'steps': args.steps,
-        'warmup': max(args.warmup, 1),
-        'ms_per_step': ms_step,
-        'higher_is_better': True,
-        'scaling': 'weak',
-        'vs_baseline': None,
-        'dtype': 'bf16',
-        'data': 'synthetic',
-        'config': {'workload': 'RRDBNet-FDConv(1,1,64,23,32) x4 inference, batch %d of %dx%d synthetic grayscale per GPU, '
-                               'bf16 (BASELINE.json configs[1])' % (B, H, W),
-                   'global_batch': world * B, 'parallelism': 'batch-sharded replicas x%d, no exchange' % world,
-                   'output_finite': finite},
-        # the FDConv conv streams 4 tensors per input channel: ~70 FLOP/B, far left of the 312 FLOP/B ridge -> HBM-bound
-        'roofline': {'bound': 'hbm', 'kernel': 'conv3x3_mfma_bf16 (average over the %d conv launches of a step)' % (conv_n // args.steps),
-                     'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_unit': 'bytes per launch (PMC, %s)' % traffic_src,
-                     'avg_launch_ms': conv_ms / max(conv_n, 1),
-                     'algorithmic_gb_per_launch': conv_bytes_step / 1e9 / max(conv_n // args.steps, 1),
-                     'mfma': {'achieved': tflops, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': tflops / BF16_MFMA_PEAK_TFLOPS, 'algorithmic_tflop_per_step': conv_flops_step / 1e12}},
-        'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},
-        'kernel_launches_per_step': {k: v[1] for k, v in prof_all.items()},
-        'kernel_ms_source': 'one extra untimed step with events around every kernel group; the conv events of the roofline are in the timed steps',
-    }
+    res = (run_tiled if args.config == 'tiled' else run_batch)(args, world, rank, dev, dist)
     if rank == 0:
-        if world == 1 and args.cpu_sample > 0 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(sd, args.cpu_sample)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -192,11 +192,12 @@ size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet* net, int dtype, int B, int H
 int sr_rrdbnet_forward(sr_rrdbnet* net, int dtype, int io_dtype, int B, int Hin, int Win, const void* x, void* y,
                        void* workspace, size_t workspace_bytes, void* stream);
 /* per-phase kernel-time attribution for bench.py: enables hipEvent timing around kernel groups
- * on the next forward; read back (ms) after a stream sync.  groups: 0 conv 1 lowpass 2 gates
- * 3 weightgen 4 layout.  enable: 0 off, 1 every group, 2 the conv group only (an event pair costs ~4 us of stream
- * time: 11 ms per config-2 forward with every group, 3 ms with the conv group alone) */
+ * on the next forward; read back (ms) after a stream sync.  groups (arrays of 8): 0 conv (trunk) 1 lowpass (trunk)
+ * 2 gates 3 weightgen 4 layout 5 head convs (conv_up1, conv_up2, conv_hr, conv_last) 6 lowpass of the head tensors
+ * 7 unused.  enable: 0 off, 1 every group, 2 the conv groups only (an event pair costs ~4 us of stream
+ * time: 11 ms per config-2 forward with every group, 3 ms with the conv groups alone) */
 int sr_rrdbnet_profile(sr_rrdbnet* net, int enable);
-int sr_rrdbnet_profile_read(sr_rrdbnet* net, float* ms5, long* launches5);
+int sr_rrdbnet_profile_read(sr_rrdbnet* net, float* ms8, long* launches8);
 
 #ifdef __cplusplus
 }

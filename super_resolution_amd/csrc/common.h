@@ -45,6 +45,28 @@ inline hipError_t lds_attr(LdsAttr& a, const void* fn, size_t bytes) {
     return e;
 }
 
+// compute units of the current device, cached per device index (a process may drive several GPUs)
+inline int device_cus(int* out) {
+    static int cus[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e);
+    int& c = cus[dev & 15];
+    if (!c) {
+        int v = 0;
+        e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return hip_fail(e);
+        c = v;
+    }
+    *out = c;
+    return SR_OK;
+}
+inline int current_device_slot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev & 15;
+}
+
 typedef uint16_t bf16_t;  // raw bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -509,20 +509,11 @@ static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates
                        const Epilogue& ep, View out, hipStream_t st) {
     const size_t ldsb = 2 * ((size_t)NPIX * 64 + 9ul * MT * 32 * 64) + (size_t)cout * sizeof(float);  // stages + bias
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
-    static size_t attr_set = 0;
-    if (attr_set < ldsb) {
-        SR_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_bf16<MT, BANDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)ldsb));
-        attr_set = ldsb;
-    }
+    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
-    static int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
-    if (!ncu) {
-        int dev = 0;
-        SR_HIP(hipGetDevice(&dev));
-        SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
+    if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
     conv3x3_mfma_bf16<MT, BANDS><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out, (unsigned)nblk);
     SR_LAUNCH_CHECK();

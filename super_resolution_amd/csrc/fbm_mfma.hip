@@ -796,11 +796,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     if (dtype != SR_BF16 || !pl->mf_ok) return SR_NOT_ELIGIBLE;
     const int H = pl->H, W = pl->W, C = x.C;
     if (!view32_ok(x, C) || !view32_ok(l2, C) || !view32_ok(l4, C) || !view32_ok(l8, C)) return SR_NOT_ELIGIBLE;
-    if (!g_mfma_cus) {
-        int dev = 0;
-        SR_HIP(hipGetDevice(&dev));
-        SR_HIP(hipDeviceGetAttribute(&g_mfma_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    if (int rc = device_cus(&g_mfma_cus)) return rc;
     const int CG = C / 32, NB = B * CG;
     const int jw = pl->mf_jw, nh = pl->mf_nh;
     h16* T = (h16*)ws;                      // [NB][H][jw][32]

@@ -486,12 +486,8 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
     if (seg.C % 16 || seg.C > 64 || !view_vec_ok(seg, 8)) return SR_NOT_ELIGIBLE;
     const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        SR_HIP(hipGetDevice(&dev));
-        SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    if (int rc = device_cus(&ncu)) return rc;
     // direct form: 64-channel segments (278 vs 405 us with five consumers at batch 16 of 512 x 512); at 32 channels the
     // T-image kernel below is as fast or faster (211 vs 246 us with four consumers), SR_AMD_GATES_DIRECT=1 forces it
     static const bool direct32 = getenv("SR_AMD_GATES_DIRECT") && atoi(getenv("SR_AMD_GATES_DIRECT")) == 1;
@@ -499,8 +495,8 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
     if ((seg.C == 64 || (seg.C == 32 && direct32)) && cl.n <= 5 && !g_gates_no_direct) {
         const int ck = seg.C / 16;
         const size_t ldsd = (size_t)GSLOTS * (seg.C * 2 + 16) + (size_t)4 * cl.n * (9 * seg.C * 2 + 16);
-        static int resident[SR_MAX_GATE_CONSUMERS + 1][2];  // persistent grid = resident workgroups
-        int& per_cu = resident[cl.n][ck == 4];
+        static int resident[16][SR_MAX_GATE_CONSUMERS + 1][2];  // persistent grid = resident workgroups, per device
+        int& per_cu = resident[current_device_slot()][cl.n][ck == 4];
 #define SR_GATES_DIRECT_V(NC, CK)                                                                                        \
     do {                                                                                                                 \
         const void* fn = (const void*)fbm_gates_acc_direct<NC, CK>;                                                      \
@@ -564,12 +560,8 @@ int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_
         SR_LDS_ATTR(lds, fbm_gates_mfma);
         const long nblk = (long)cdiv(H, GMH) * cdiv(W, GMW) * B;
         if (nblk >= (1L << 31)) return SR_ERR_ARG;
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            SR_HIP(hipGetDevice(&dev));
-            SR_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        int ncu = 0;
+        if (int rc = device_cus(&ncu)) return rc;
         const long per_cu = std::max<long>(1, std::min<long>(4, (160 * 1024) / (long)lds));
         const unsigned grid = (unsigned)std::min<long>(nblk, per_cu * ncu);
         fbm_gates_mfma<<<dim3(grid), 256, lds, st>>>(

@@ -54,7 +54,8 @@ struct sr_rrdbnet {
 
 namespace {
 
-enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4 };
+// profile groups: head = conv_up1 / conv_up2 / conv_hr / conv_last (the 2x / 4x resolution convs), lowpass_hr = their low-pass launches
+enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4, G_HEAD = 5, G_LOWPASS_HR = 6, G_NGROUPS = 8 };
 
 struct Layout {
     size_t in0, f0, trunk[3], xg[4], band64, bandg[4], gates, logit[5], pooled, wdyn, fft, u1, band_u1, u2, u3, band_hr, outp;
@@ -97,7 +98,10 @@ Layout make_layout(const sr_rrdbnet* net, int dtype, int B, int H, int W) {
         for (int i = 0; i < 5; ++i) L.logit[i] = carve(n1 * 3 * sizeof(float));  // dense-block gate accumulators
         const int cmax = net->nf + 4 * net->gc;
         L.pooled = carve((size_t)B * cmax * sizeof(float));
-        L.wdyn = carve((size_t)B * 9 * net->nf * cmax * es);
+        size_t wmax = 0;  // largest cout * cin over the layers (conv4 beats conv5 when num_grow_ch > num_feat)
+        for (const sr_layer_params& lp : net->layers)
+            if ((size_t)lp.cout * lp.cin > wmax) wmax = (size_t)lp.cout * lp.cin;
+        L.wdyn = carve((size_t)B * 9 * wmax * es);
         L.fft = carve(fft_ws_need(net, B, H, W));
     }
     L.total = off;
@@ -112,6 +116,10 @@ struct Run {
     Layout L;
     size_t es;
     int rc = SR_OK;
+    // gate logits of the current dense block are complete up to this segment (set by the rdb_k == 0 accumulate launch,
+    // cleared by any layer of the block that did not go through the accumulate kernel): the segment-wise path adds
+    // only the newest segment onto L.logit[], so it must never run on accumulators an earlier layer did not fill
+    int acc_valid_upto = -1;
 
     // cb = channels per block (0: NHWC).  Trunk tensors use blocks of 32 (one conv K-chunk = one contiguous 64-byte
     // run per pixel); the 2x / 4x tensors blocks of 8, so the FFT passes stream whole rows.
@@ -122,7 +130,7 @@ struct Run {
     bool prof_open = false;
     void prof_begin(int group, hipStream_t on = nullptr) {
         prof_open = false;
-        if (!net->prof || rc != SR_OK || (net->prof == 2 && group != G_CONV)) return;
+        if (!net->prof || rc != SR_OK || (net->prof == 2 && group != G_CONV && group != G_HEAD)) return;
         prof_open = true;
         if (!on) on = st;
         if (net->ev_used == net->events.size()) {
@@ -152,7 +160,7 @@ struct Run {
         sr_fbm_plan* pl = plan(res);
         if (!pl || ups < 0 || ups > 1) { rc = SR_ERR_STATE; return; }
         float* pooled = (float*)(ws + L.pooled) + pooled_off;
-        prof_begin(G_LOWPASS);
+        prof_begin(res > 0 ? G_LOWPASS_HR : G_LOWPASS);
         rc = fbm_lowpass_launch(pl, dtype, B, t.x, ups, t.band[0], t.band[1], t.band[2], pooled,
                                 net->nf + 4 * net->gc, ws + L.fft, L.total - L.fft, st);
         prof_end();
@@ -167,6 +175,9 @@ struct Run {
         if (rc != SR_OK) return;
         const sr_layer_params& lp = net->layers[li];
         const int Hc = H << res, Wc = W << res;
+        const bool head = li >= 15 * net->nb + 2;          // conv_up1, conv_up2, conv_hr, conv_last
+        if (rdb_k == 0) acc_valid_upto = -1;              // a new dense block starts: nothing accumulated yet
+        if (rdb_k >= 0 && !lp.active) acc_valid_upto = -2;  // a plain layer inside the block accumulates nothing
         Concat c{};
         c.nseg = nseg;
         c.bands = lp.active ? 1 : 0;
@@ -201,7 +212,7 @@ struct Run {
             if (fork && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(G_GATES);
             bool done = false;
-            if (rdb_k >= 0 && dtype == SR_BF16 && nseg == rdb_k + 1) {
+            if (rdb_k >= 0 && dtype == SR_BF16 && nseg == rdb_k + 1 && acc_valid_upto == rdb_k - 1) {
                 GateConsList cl{};
                 const int cstart = c.cstart[rdb_k];  // first concat channel of the newest segment
                 bool okc = true;
@@ -223,16 +234,17 @@ struct Run {
                     else if (r2 != SR_NOT_ELIGIBLE) rc = r2;
                 }
             }
+            if (rdb_k >= 0) acc_valid_upto = done ? rdb_k : -2;  // -2: this block's accumulators are incomplete for good
             if (!done && rc == SR_OK) rc = fbm_gates_launch(dtype, B, Hc, Wc, c, lp, gates, st);
             prof_end();
             if (rc != SR_OK) return;
             if (fork && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
-            prof_begin(G_CONV);
+            prof_begin(head ? G_HEAD : G_CONV);
             rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, lp.cout, ep, out, st);
             prof_end();
         } else {
             if (!lp.wpacked) { rc = SR_ERR_STATE; return; }
-            prof_begin(G_CONV);
+            prof_begin(head ? G_HEAD : G_CONV);
             rc = conv3x3_launch(dtype, B, Hc, Wc, c, nullptr, lp.wpacked, 0, lp.cout, ep, out, st);
             prof_end();
         }
@@ -487,9 +499,11 @@ extern "C" int sr_rrdbnet_profile(sr_rrdbnet* n, int enable) {
     return SR_OK;
 }
 
-extern "C" int sr_rrdbnet_profile_read(sr_rrdbnet* n, float* ms5, long* launches5) {
-    SR_REQUIRE(n && ms5 && launches5);
-    for (int i = 0; i < 5; ++i) { ms5[i] = 0.f; launches5[i] = 0; }
+extern "C" int sr_rrdbnet_profile_read(sr_rrdbnet* n, float* ms8, long* launches8) {
+    SR_REQUIRE(n && ms8 && launches8);
+    float* ms5 = ms8;
+    long* launches5 = launches8;
+    for (int i = 0; i < G_NGROUPS; ++i) { ms5[i] = 0.f; launches5[i] = 0; }
     for (size_t i = 0; i < n->ev_used; ++i) {
         float ms = 0.f;
         SR_HIP(hipEventSynchronize(n->events[i].b));

@@ -1,92 +1,105 @@
-"""RealESRGANer -- drop-in for Real-ESRGAN-master/realesrgan/utils.py:14-263 of the reference.
+"""RealESRGANer -- drop-in for Real-ESRGAN-master/realesrgan/utils.py:14-313 of the reference.
 
 Same constructor, attributes (`scale, tile_size, tile_pad, pre_pad, mod_scale, half, device, model,
 img, output, mod_pad_h, mod_pad_w`) and methods (`dni, pre_process, process, tile_process,
-post_process, enhance`).  Differences, all behind the same interface:
+post_process, enhance`), plus `PrefetchReader` / `IOConsumer` (utils.py:266-313).  Differences, all
+behind the same interface:
   * `half=True` selects bf16 MFMA compute inside the network (parameters stay float32); the image
     tensors handed to the model are float32 either way;
   * cv2 is not required: the colour conversions of `enhance` are numpy (COLOR_BGR2GRAY = 0.114 B +
-    0.587 G + 0.299 R); `outscale != scale` (cv2 LANCZOS4 resize, utils.py:256-261) raises;
+    0.587 G + 0.299 R) and the `outscale != scale` resize (cv2.INTER_LANCZOS4, utils.py:256-261) is
+    `lanczos4_resize` below -- both PARITY UNPINNED (cv2 is absent from the build image; OpenCV's
+    8-bit path interpolates in 11-bit fixed point, this one in float32, so results may differ by 1 LSB);
   * when torch.distributed is initialised with world_size > 1 and `shard_tiles=True`, tile_process
     splits the tiles over the ranks (largest first, round-robin) and rank 0 gathers the pasted
-    centres with point-to-point transfers -- tiles are independent, so there is no collective;
-  * a failed tile raises instead of pasting a stale tile (utils.py:158-162 latent bug).
+    centres with point-to-point transfers -- tiles are independent, so there is no collective.  Only
+    rank 0 holds the assembled image: on the other ranks `self.output` is None after tile_process and
+    `enhance` returns `(None, img_mode)`;
+  * `tile_batch` (default 1 = the reference's one tile at a time, same peak memory) runs that many
+    tiles of equal window size through the network as one batch;
+  * a failed tile raises instead of pasting a stale tile (utils.py:158-162 latent bug);
+  * device -> host copies of results go through a pinned staging buffer.
 """
 import math
+import queue
+import threading
 
 import numpy as np
 import torch
 from torch.nn import functional as F
 
 
+def _load_checkpoint(path, loc='cpu'):
+    if path.startswith('https://'):
+        raise RuntimeError('no network access: download %s yourself and pass the local path' % path)
+    return torch.load(path, map_location=torch.device(loc), weights_only=True)
+
+
 class RealESRGANer():
 
     def __init__(self, scale, model_path, dni_weight=None, model=None, tile=0, tile_pad=10, pre_pad=10, half=False,
-                 device=None, gpu_id=None, shard_tiles=False, tile_batch=8):
+                 device=None, gpu_id=None, shard_tiles=False, tile_batch=1):
         """The reference signature (utils.py:29-40) plus two keyword extensions: `shard_tiles` deals the tiles over the
-        ranks of an initialised process group, `tile_batch` runs up to that many tiles of equal window size through the
-        network in one batch (every statistic of the network is per sample, so the result is the one-by-one result)."""
-        self.scale = scale
-        self.tile_batch = max(1, int(tile_batch))
-        self.tile_size = tile
-        self.tile_pad = tile_pad
-        self.pre_pad = pre_pad
+        ranks of an initialised process group; `tile_batch` > 1 runs that many tiles of equal window size through the
+        network in one batch (every statistic of the network is per sample, so the result is the one-by-one result,
+        but the executor workspace grows by that factor -- opt-in, the default keeps the reference's memory bound)."""
+        if model is None:
+            raise ValueError('RealESRGANer needs the network (model=...)')
+        self.scale, self.tile_size, self.tile_pad, self.pre_pad = scale, tile, tile_pad, pre_pad
         self.mod_scale = None
         self.half = half
         self.shard_tiles = shard_tiles
-        if gpu_id:
-            self.device = torch.device(f'cuda:{gpu_id}' if torch.cuda.is_available() else 'cpu') if device is None else device
+        self.tile_batch = max(1, int(tile_batch))
+        self.img = self.output = None
+        self.mod_pad_h = self.mod_pad_w = 0
+        if device is not None:
+            self.device = device
         else:
-            self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu') if device is None else device
-        if model is None:
-            raise ValueError('RealESRGANer needs the network (model=...)')
-        if model_path is not None:
-            if isinstance(model_path, list):
-                assert len(model_path) == len(dni_weight), 'model_path and dni_weight should have the save length.'
-                loadnet = self.dni(model_path[0], model_path[1], dni_weight)
-            else:
-                if model_path.startswith('https://'):
-                    raise RuntimeError('no network access: download %s yourself and pass the local path' % model_path)
-                loadnet = torch.load(model_path, map_location=torch.device('cpu'), weights_only=True)
-            keyname = 'params_ema' if 'params_ema' in loadnet else 'params'
-            model.load_state_dict(loadnet[keyname], strict=True)
-        model.eval()
-        self.model = model.to(self.device)
-        if self.half:
+            name = 'cuda:%d' % gpu_id if gpu_id else 'cuda'   # gpu_id 0 / None: the current device, as the reference
+            self.device = torch.device(name if torch.cuda.is_available() else 'cpu')
+        if isinstance(model_path, (list, tuple)):
+            if dni_weight is None or len(model_path) != len(dni_weight):
+                raise AssertionError('model_path and dni_weight must be lists of the same length')
+            state = self.dni(model_path[0], model_path[1], dni_weight)
+        elif model_path is not None:
+            state = _load_checkpoint(model_path)
+        else:
+            state = None
+        if state is not None:
+            model.load_state_dict(state['params_ema' if 'params_ema' in state else 'params'], strict=True)
+        self.model = model.eval().to(self.device)
+        if half:
             if hasattr(self.model, 'compute_dtype'):
                 self.model.compute_dtype = torch.bfloat16
             else:
                 self.model = self.model.half()
+        self._pinned = None
 
     def dni(self, net_a, net_b, dni_weight, key='params', loc='cpu'):
-        """Deep network interpolation of two checkpoints (utils.py:77-86)."""
-        net_a = torch.load(net_a, map_location=torch.device(loc), weights_only=True)
-        net_b = torch.load(net_b, map_location=torch.device(loc), weights_only=True)
-        for k, v_a in net_a[key].items():
-            net_a[key][k] = dni_weight[0] * v_a + dni_weight[1] * net_b[key][k]
-        return net_a
+        """Deep network interpolation (utils.py:77-86): every entry of `key` becomes w0 * a + w1 * b."""
+        a, b = _load_checkpoint(net_a, loc), _load_checkpoint(net_b, loc)
+        wa, wb = dni_weight
+        a[key] = {name: wa * va + wb * b[key][name] for name, va in a[key].items()}
+        return a
 
     def _model_dtype(self):
         return torch.float16 if (self.half and not hasattr(self.model, 'compute_dtype')) else torch.float32
 
+    # ------------------------------------------------------------------ geometry (utils.py:88-191)
     def pre_process(self, img):
-        """HWC float numpy -> 1CHW tensor on the device, reflect pre-pad and mod-pad (utils.py:88-111)."""
-        img = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (2, 0, 1)))).float()
-        self.img = img.unsqueeze(0).to(self.device).to(self._model_dtype())
-        if self.pre_pad != 0:
-            self.img = F.pad(self.img, (0, self.pre_pad, 0, self.pre_pad), 'reflect')
-        if self.scale == 2:
-            self.mod_scale = 2
-        elif self.scale == 1:
-            self.mod_scale = 4
+        """HWC float numpy -> self.img, a 1CHW tensor on the device: reflect pre-pad on the right / bottom, then the
+        reflect mod-pad that scale 2 / 1 networks (pixel_unshuffle by 2 / 4) need (utils.py:88-111)."""
+        chw = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).float()
+        t = chw[None].to(self.device).to(self._model_dtype())
+        if self.pre_pad:
+            t = F.pad(t, (0, self.pre_pad, 0, self.pre_pad), 'reflect')
+        self.mod_scale = {2: 2, 1: 4}.get(self.scale, self.mod_scale)
         if self.mod_scale is not None:
-            self.mod_pad_h, self.mod_pad_w = 0, 0
-            _, _, h, w = self.img.size()
-            if h % self.mod_scale != 0:
-                self.mod_pad_h = self.mod_scale - h % self.mod_scale
-            if w % self.mod_scale != 0:
-                self.mod_pad_w = self.mod_scale - w % self.mod_scale
-            self.img = F.pad(self.img, (0, self.mod_pad_w, 0, self.mod_pad_h), 'reflect')
+            h, w = t.shape[-2:]
+            self.mod_pad_h = -h % self.mod_scale
+            self.mod_pad_w = -w % self.mod_scale
+            t = F.pad(t, (0, self.mod_pad_w, 0, self.mod_pad_h), 'reflect')
+        self.img = t
 
     def process(self):
         self.output = self.model(self.img)
@@ -117,47 +130,50 @@ class RealESRGANer():
             out = self.model(self.img[:, :, py0:py1, px0:px1])
         return out[:, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s]
 
-    def _run_tiles(self, wins, idxs):
-        """{tile index: output core} for the tiles `idxs`; tiles with equal window size share batches of `tile_batch`."""
+    def _run_tiles(self, wins, idxs, sink=None):
+        """Output cores of the tiles `idxs`; tiles with equal window size share batches of `tile_batch`.  With `sink`
+        every core is handed to sink(index, tensor) as soon as it exists (nothing is kept), else a dict is returned."""
         groups = {}
         for i in idxs:
             (py0, py1, px0, px1) = wins[i][0]
             groups.setdefault((py1 - py0, px1 - px0), []).append(i)
         s, nb, done = self.scale, self.img.shape[0], {}
+        put = sink if sink is not None else done.__setitem__
         for members in groups.values():
             for k in range(0, len(members), self.tile_batch):
                 part = members[k:k + self.tile_batch]
                 if len(part) == 1:
-                    done[part[0]] = self._run_tile(wins[part[0]])
+                    put(part[0], self._run_tile(wins[part[0]]))
                     continue
                 crops = torch.cat([self.img[:, :, wins[i][0][0]:wins[i][0][1], wins[i][0][2]:wins[i][0][3]] for i in part], 0)
                 with torch.no_grad():
                     out = self.model(crops)
                 for j, i in enumerate(part):
                     (y0, y1, x0, x1), (oy, ox) = wins[i][1], wins[i][2]
-                    done[i] = out[j * nb:(j + 1) * nb, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s]
+                    put(i, out[j * nb:(j + 1) * nb, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s])
         return done
 
     def tile_process(self):
         """Crop overlapping tiles, run each, paste the un-padded centres (utils.py:117-180)."""
         batch, channel, height, width = self.img.shape
         s = self.scale
-        self.output = self.img.new_zeros((batch, channel, height * s, width * s))
         wins = self.tile_windows()
         import torch.distributed as dist
         world = dist.get_world_size() if (self.shard_tiles and dist.is_available() and dist.is_initialized()) else 1
-        if world == 1:
-            for i, t in self._run_tiles(wins, range(len(wins))).items():
-                (y0, y1, x0, x1) = wins[i][1]
-                self.output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = t
-            return
-        rank = dist.get_rank()
-        mine = self.shard_of(wins, rank, world)
-        done = {i: t.contiguous() for i, t in self._run_tiles(wins, mine).items()}
+        rank = dist.get_rank() if world > 1 else 0
+
+        def paste(i, t):
+            (y0, y1, x0, x1) = wins[i][1]
+            self.output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = t
+
         if rank == 0:
-            for i, t in done.items():
-                (y0, y1, x0, x1) = wins[i][1]
-                self.output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = t
+            self.output = self.img.new_zeros((batch, channel, height * s, width * s))
+        if world == 1:
+            self._run_tiles(wins, range(len(wins)), sink=paste)
+            return
+        mine = self.shard_of(wins, rank, world)
+        if rank == 0:
+            # post every receive first, so the peers' sends complete while this rank is still computing its own tiles
             bufs, reqs = [], []
             for src in range(1, world):
                 for i in self.shard_of(wins, src, world):
@@ -165,24 +181,49 @@ class RealESRGANer():
                     buf = self.img.new_empty((batch, channel, (y1 - y0) * s, (x1 - x0) * s))
                     reqs.append(dist.irecv(buf, src=src, tag=i))
                     bufs.append((i, buf))
+            self._run_tiles(wins, mine, sink=paste)
             for r in reqs:
                 r.wait()
             for i, buf in bufs:
-                (y0, y1, x0, x1) = wins[i][1]
-                self.output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = buf
+                paste(i, buf)
         else:
-            reqs = [dist.isend(done[i], dst=0, tag=i) for i in mine]
+            self.output = None  # only rank 0 assembles the image
+            reqs, keep = [], []
+
+            def send(i, t):
+                t = t.contiguous()
+                keep.append(t)
+                reqs.append(dist.isend(t, dst=0, tag=i))
+            self._run_tiles(wins, mine, sink=send)
             for r in reqs:
                 r.wait()
 
     def post_process(self):
+        """Crop the mod-pad and the pre-pad off the upscaled image (utils.py:182-191); None on ranks without the image."""
+        if self.output is None:
+            return None
+        cut_h = cut_w = 0
         if self.mod_scale is not None:
-            _, _, h, w = self.output.size()
-            self.output = self.output[:, :, 0:h - self.mod_pad_h * self.scale, 0:w - self.mod_pad_w * self.scale]
-        if self.pre_pad != 0:
-            _, _, h, w = self.output.size()
-            self.output = self.output[:, :, 0:h - self.pre_pad * self.scale, 0:w - self.pre_pad * self.scale]
+            cut_h, cut_w = self.mod_pad_h * self.scale, self.mod_pad_w * self.scale
+        cut_h += self.pre_pad * self.scale
+        cut_w += self.pre_pad * self.scale
+        h, w = self.output.shape[-2:]
+        self.output = self.output[:, :, 0:h - cut_h, 0:w - cut_w]
         return self.output
+
+    def _to_host(self, t):
+        """Device tensor -> float32 numpy through a pinned staging buffer (a pageable .cpu() of a 16384^2 x 3 image
+        costs seconds of host time)."""
+        t = t.float().contiguous()
+        if not t.is_cuda:
+            return t.numpy()
+        n = t.numel()
+        if self._pinned is None or self._pinned.numel() < n:
+            self._pinned = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        stage = self._pinned[:n].view(t.shape)
+        stage.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return stage.numpy().copy()
 
     def _upscale(self, img):
         self.pre_process(img)
@@ -191,50 +232,155 @@ class RealESRGANer():
         else:
             self.process()
         out = self.post_process()
-        out = out.data.squeeze().float().cpu().clamp_(0, 1).numpy()
-        return np.transpose(out[[2, 1, 0], :, :], (1, 2, 0))
+        if out is None:
+            return None
+        out = np.clip(self._to_host(out.data.squeeze(0)), 0.0, 1.0)
+        return np.ascontiguousarray(out[::-1].transpose(1, 2, 0))  # RGB planes -> H x W x BGR
 
     @torch.no_grad()
     def enhance(self, img, outscale=None, alpha_upsampler='realesrgan'):
         """img: HxW[xC] numpy (BGR[A] / gray; uint8, uint16 or float) -> (upscaled numpy, img_mode) (utils.py:193-263)."""
-        if outscale is not None and float(outscale) != float(self.scale):
-            raise NotImplementedError('outscale != scale needs cv2.resize(LANCZOS4); resize the result yourself')
+        h_in, w_in = img.shape[:2]
         img = img.astype(np.float32)
-        if np.max(img) > 256:
-            max_range = 65535
+        sixteen = np.max(img) > 256
+        if sixteen:
             print('\tInput is a 16-bit image')
-        else:
-            max_range = 255
-        img = img / max_range
+        full = 65535 if sixteen else 255
+        img = img / full
         alpha = None
-        if len(img.shape) == 2:
-            img_mode = 'L'
-            img = np.stack([img, img, img], axis=-1)
+        if img.ndim == 2:
+            img_mode, rgb = 'L', np.repeat(img[:, :, None], 3, axis=2)
         elif img.shape[2] == 4:
-            img_mode = 'RGBA'
-            alpha = img[:, :, 3]
-            img = img[:, :, 2::-1]
-            if alpha_upsampler == 'realesrgan':
-                alpha = np.stack([alpha, alpha, alpha], axis=-1)
+            img_mode, rgb, alpha = 'RGBA', img[:, :, 2::-1], img[:, :, 3]
         else:
-            img_mode = 'RGB'
-            img = img[:, :, ::-1]
-        output_img = self._upscale(img)
-        if img_mode == 'L':
-            output_img = _bgr2gray(output_img)
+            img_mode, rgb = 'RGB', img[:, :, ::-1]
+        out = self._upscale(rgb)
+        out_alpha = None
         if img_mode == 'RGBA':
             if alpha_upsampler == 'realesrgan':
-                output_alpha = _bgr2gray(self._upscale(alpha))
-            else:
+                a3 = self._upscale(np.repeat(alpha[:, :, None], 3, axis=2))
+                out_alpha = None if a3 is None else _bgr2gray(a3)
+            else:  # cv2.resize(INTER_LINEAR) of the reference: half-pixel-centre bilinear
                 a = torch.from_numpy(np.ascontiguousarray(alpha))[None, None]
-                output_alpha = F.interpolate(a, scale_factor=self.scale, mode='bilinear', align_corners=False)[0, 0].numpy()
-            output_img = np.concatenate([output_img, output_alpha[..., None]], axis=-1)
-        if max_range == 65535:
-            output = (output_img * 65535.0).round().astype(np.uint16)
-        else:
-            output = (output_img * 255.0).round().astype(np.uint8)
-        return output, img_mode
+                out_alpha = F.interpolate(a, scale_factor=self.scale, mode='bilinear', align_corners=False)[0, 0].numpy()
+        if out is None:
+            return None, img_mode
+        if img_mode == 'L':
+            out = _bgr2gray(out)
+        elif img_mode == 'RGBA':
+            out = np.concatenate([out, out_alpha[..., None]], axis=-1)
+        out = (out * float(full)).round().astype(np.uint16 if sixteen else np.uint8)
+        if outscale is not None and float(outscale) != float(self.scale):
+            out = lanczos4_resize(out, int(h_in * outscale), int(w_in * outscale))
+        return out, img_mode
 
 
 def _bgr2gray(img):
     return (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).astype(np.float32)
+
+
+def _lanczos4_taps(n_out, n_in):
+    """Source indices (n_out, 8) and weights (n_out, 8) of OpenCV's INTER_LANCZOS4 along one axis: source coordinate
+    (dst + 0.5) * n_in / n_out - 0.5, taps floor - 3 .. floor + 4, Lanczos a = 4 weights normalised to sum 1,
+    indices clamped to the image (BORDER_REPLICATE, what cv2.resize uses)."""
+    pos = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+    base = np.floor(pos)
+    frac = pos - base
+    offs = np.arange(-3, 5, dtype=np.float64)
+    x = frac[:, None] - offs[None, :]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        w = np.where(np.abs(x) < 1e-12, 1.0, np.sin(np.pi * x) * np.sin(np.pi * x / 4) / (np.pi * np.pi * x * x / 4))
+    w = np.where(np.abs(x) < 4, w, 0.0)
+    w = w / w.sum(axis=1, keepdims=True)
+    idx = np.clip(base[:, None].astype(np.int64) + offs[None, :].astype(np.int64), 0, n_in - 1)
+    return idx, w.astype(np.float32)
+
+
+def lanczos4_resize(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LANCZOS4) restated in float32 (utils.py:256-261):
+    separable 8-tap Lanczos, replicate border, result rounded and saturated to the input's integer dtype.
+    PARITY UNPINNED: cv2 is not installed here and no reference fixture holds a resized image."""
+    src = img.astype(np.float32)
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[:, :, None]
+    iy, wy = _lanczos4_taps(out_h, src.shape[0])
+    ix, wx = _lanczos4_taps(out_w, src.shape[1])
+    rows = np.einsum('hkwc,hk->hwc', src[iy], wy)                 # (out_h, W, C)
+    out = np.einsum('hwkc,wk->hwc', rows[:, ix], wx)              # (out_h, out_w, C)
+    if squeeze:
+        out = out[:, :, 0]
+    if np.issubdtype(img.dtype, np.integer):
+        info = np.iinfo(img.dtype)
+        out = np.clip(np.rint(out), info.min, info.max).astype(img.dtype)
+    return out
+
+
+def _read_image(path):
+    """cv2.imread(path, cv2.IMREAD_UNCHANGED) stand-in on PIL: numpy HxW (gray), HxWx3 BGR or HxWx4 BGRA;
+    `.npy` files are loaded as they are (any dtype)."""
+    if str(path).endswith('.npy'):
+        return np.load(path)
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    if a.ndim == 3 and a.shape[2] >= 3:
+        a = np.concatenate([a[:, :, 2::-1], a[:, :, 3:]], axis=2)
+    return np.ascontiguousarray(a)
+
+
+def _write_image(path, img):
+    if str(path).endswith('.npy'):
+        np.save(path, img)
+        return
+    from PIL import Image
+    a = img
+    if a.ndim == 3 and a.shape[2] >= 3:
+        a = np.concatenate([a[:, :, 2::-1], a[:, :, 3:]], axis=2)
+    Image.fromarray(np.ascontiguousarray(a)).save(path)
+
+
+class PrefetchReader(threading.Thread):
+    """Reads the images of `img_list` ahead of the consumer on a thread (utils.py:266-293); iterate to receive them.
+
+    `read_fn(path) -> numpy` replaces cv2.imread (default: PIL / .npy, BGR channel order like cv2)."""
+
+    def __init__(self, img_list, num_prefetch_queue, read_fn=None):
+        super().__init__(daemon=True)
+        self.que = queue.Queue(num_prefetch_queue)
+        self.img_list = img_list
+        self.read_fn = read_fn or _read_image
+
+    def run(self):
+        for path in self.img_list:
+            self.que.put(self.read_fn(path))
+        self.que.put(None)
+
+    def __next__(self):
+        item = self.que.get()
+        if item is None:
+            raise StopIteration
+        return item
+
+    def __iter__(self):
+        return self
+
+
+class IOConsumer(threading.Thread):
+    """Writes results handed over a queue as {'output': numpy, 'save_path': str} until it receives 'quit'
+    (utils.py:296-313).  `write_fn(path, img)` replaces cv2.imwrite (default: PIL / .npy)."""
+
+    def __init__(self, opt, que, qid, write_fn=None):
+        super().__init__(daemon=True)
+        self._queue = que
+        self.qid = qid
+        self.opt = opt
+        self.write_fn = write_fn or _write_image
+
+    def run(self):
+        while True:
+            msg = self._queue.get()
+            if isinstance(msg, str) and msg == 'quit':
+                break
+            self.write_fn(msg['save_path'], msg['output'])
+        print(f'IO worker {self.qid} is done.')

@@ -115,8 +115,13 @@ class RRDBNet(nn.Module):
 
     def forward(self, x):
         L.require_gpu(x, 'RRDBNet.forward')
-        if self.training and any(isinstance(m, FDConv) and m.fdconv_active for m in self.conv_layers()):
-            raise NotImplementedError('RRDBNet-FDConv training is not implemented yet (inference only)')
+        if self.training and (torch.is_grad_enabled() or
+                              any(isinstance(m, FDConv) and m.fdconv_active for m in self.conv_layers())):
+            # the executor below enqueues HIP kernels without an autograd graph (a tensor without grad_fn would make
+            # loss.backward() fail later, or train nothing) and evaluates KSM_Global's BatchNorm on its running
+            # statistics; the differentiable train-mode path is super_resolution_amd.train
+            raise NotImplementedError('RRDBNet.forward in train() mode records no autograd graph; use '
+                                      'super_resolution_amd.train (training step) or call .eval() / torch.no_grad()')
         io_dt = x.dtype
         dt = self.compute_dtype or io_dt
         L.dtype_code(io_dt)
@@ -136,10 +141,10 @@ class RRDBNet(nn.Module):
         L.check(L.lib().sr_rrdbnet_profile(self._sr.h, int(enable)), 'sr_rrdbnet_profile')
 
     def profile_read(self):
-        ms = (C.c_float * 5)()
-        n = (C.c_long * 5)()
+        ms = (C.c_float * 8)()
+        n = (C.c_long * 8)()
         L.check(L.lib().sr_rrdbnet_profile_read(self._sr.h, ms, n), 'sr_rrdbnet_profile_read')
-        names = ('conv', 'lowpass', 'gates', 'weightgen', 'layout')
+        names = ('conv', 'lowpass', 'gates', 'weightgen', 'layout', 'head', 'lowpass_hr')
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
 

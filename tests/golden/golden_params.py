@@ -87,3 +87,23 @@ def rrdbnet_state(num_in_ch, num_out_ch, num_feat, num_block, num_grow_ch, seed,
         for k, v in lp.items():
             sd[name + '.' + k] = v
     return sd
+
+
+def srvgg_state(num_in_ch, num_out_ch, num_feat, num_conv, upscale, seed, act_type='prelu'):
+    """Flat numpy state_dict of SRVGGNetCompact (Real-ESRGAN-master/realesrgan/archs/srvgg_arch.py:22-58):
+    body.0 conv, body.1 act, then (conv, act) x num_conv, last conv -> num_out_ch * upscale^2."""
+    r = np.random.RandomState(seed)
+    sd = {}
+    idx = 0
+    chans = [(num_in_ch, num_feat)] + [(num_feat, num_feat)] * num_conv
+    for cin, cout in chans:
+        sd['body.%d.weight' % idx] = (r.standard_normal((cout, cin, 3, 3)) * np.sqrt(1.6 / (cin * 9.0))).astype(np.float32)
+        sd['body.%d.bias' % idx] = (0.05 * r.standard_normal(cout)).astype(np.float32)
+        idx += 1
+        if act_type == 'prelu':
+            sd['body.%d.weight' % idx] = (0.25 + 0.2 * r.standard_normal(cout)).astype(np.float32)
+        idx += 1
+    cout = num_out_ch * upscale * upscale
+    sd['body.%d.weight' % idx] = (r.standard_normal((cout, num_feat, 3, 3)) * 0.5 / np.sqrt(num_feat * 9.0)).astype(np.float32)
+    sd['body.%d.bias' % idx] = (0.05 * r.standard_normal(cout)).astype(np.float32)
+    return sd

@@ -1,0 +1,300 @@
+"""GPU parity at the depth and at the window sizes the BASELINE configs run (round-2 additions).
+
+  * 23-block RRDBNet-FDConv (config 2's network) in fp32 against the CPU oracle, with the module constructors' own
+    seeded initialisation ("realistic": contractive like a trained checkpoint) and with the O(1)-perturbed set;
+  * north_star's bf16 criterion (PSNR delta <= 0.05 dB) on the realistic 23-block network;
+  * config 3's windows: RealESRGANer(tile=512, tile_pad=10) produces 522- and 532-pixel windows; an FDConv network
+    runs them tile by tile against the oracle, and the low-pass planes are checked at 1x, 2x and 4x of those sizes;
+  * the dense-block gate accumulation outside the default nf=64 / gc=32 shape, odd sizes in bf16, and
+    tile batching with per-sample dynamic weights.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_params as gp
+from oracle import fdconv_ref as fr
+from oracle.rrdbnet_ref import rrdbnet_forward
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4       # north_star: fp32 max-abs-err <= 1e-4
+PSNR_DELTA_DB = 0.05  # north_star: bf16 PSNR delta <= 0.05 dB
+
+
+def t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def psnr(a, b):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 99.0 if mse == 0 else 20 * math.log10(1.0 / math.sqrt(mse))
+
+
+@pytest.fixture(scope='module')
+def sra():
+    import super_resolution_amd as m
+    from super_resolution_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return m
+
+
+def realistic_net(sra, args, seed):
+    """The network as the owner script builds it (train/train_realESRGAN_fdconv_1.py:100-101): RRDBNet's own init
+    (kaiming x 0.1), every conv replaced by a freshly initialised FDConv.  Returns (GPU net, CPU state_dict)."""
+    torch.manual_seed(seed)
+    net = sra.replace_conv_with_fdconv(sra.RRDBNet(*args))
+    # give the BatchNorm running statistics and the 1e-6 heads something to do without leaving the contractive regime
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if any(s in name for s in ('spatial_fc.weight', 'kernel_fc.weight', 'channel_fc.weight', 'KSM_Local.conv.weight',
+                                       'freq_weight_conv_list')) and p.dim() > 1:
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        for name, b in net.named_buffers():
+            if name.endswith('running_mean'):
+                b.add_(0.05 * torch.randn(b.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return net.eval().cuda(), sd
+
+
+def test_23_blocks_fp32_vs_oracle_realistic_weights(sra):
+    net, sd = realistic_net(sra, (1, 1, 4, 64, 23, 32), seed=1)
+    for shape, seed in (((1, 1, 64, 64), 80), ((2, 1, 96, 80), 81)):
+        x = torch.from_numpy(gp.image_input(shape, seed))
+        with torch.no_grad():
+            y = net(x.cuda()).cpu()
+            ref = rrdbnet_forward(sd, x)
+        err = (y - ref).abs().max().item()
+        print('23-block RRDBNet-FDConv fp32 %s: max|gpu - oracle| = %.3e (|y| max %.3f)' % (shape, err, ref.abs().max().item()))
+        assert err < FP32_TOL, (shape, err)
+
+
+def test_23_blocks_fp32_vs_oracle_perturbed_weights(sra):
+    """The O(1)-perturbed parameter set of the bench: 349 stacked layers with data-dependent weights amplify rounding, so
+    the yardstick is the oracle itself -- fp32 oracle against fp64 oracle gives the noise floor of ANY fp32 evaluation
+    of this network, and the GPU must stay within a small multiple of it (and within 1e-4 when the floor allows)."""
+    sd = t(gp.rrdbnet_state(1, 1, 64, 23, 32, seed=1234))
+    net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 23, 32))
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().cuda()
+    x = torch.from_numpy(gp.image_input((1, 1, 64, 64), 82))
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+        ref32 = rrdbnet_forward(sd, x)
+        ref64 = rrdbnet_forward(sd, x.double(), dtype=torch.float64)
+    floor = (ref32.double() - ref64).abs().max().item()
+    err = (y.double() - ref64).abs().max().item()
+    scale = ref64.abs().max().item()
+    print('perturbed 23-block net: |gpu32 - oracle64| = %.3e, |oracle32 - oracle64| = %.3e, |y| max %.3e' % (err, floor, scale))
+    assert err <= max(FP32_TOL, 8.0 * floor), (err, floor)
+
+
+def test_23_blocks_bf16_psnr_delta_realistic_weights(sra):
+    """north_star's bf16 criterion at config depth: 23 blocks, 2 x 1 x 128 x 128 (trunk on the MFMA low-pass)."""
+    net, sd = realistic_net(sra, (1, 1, 4, 64, 23, 32), seed=2)
+    x = torch.from_numpy(gp.image_input((2, 1, 128, 128), 83))
+    with torch.no_grad():
+        ref = rrdbnet_forward(sd, x)
+        yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
+    target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
+    p_ref, p_bf, p_direct = psnr(ref.clamp(0, 1), target), psnr(yb.clamp(0, 1), target), psnr(yb, ref)
+    print('23-block bf16: PSNR vs target fp32 oracle %.3f dB, bf16 GPU %.3f dB; bf16-vs-fp32 direct %.1f dB' % (p_ref, p_bf, p_direct))
+    assert abs(p_ref - p_bf) <= PSNR_DELTA_DB
+    assert p_direct > 35.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3 windows
+# ---------------------------------------------------------------------------------------------------------------
+def _lowpass_gpu(L, x_nchw, dtype, ups=0):
+    """sr_fbm_lowpass on an NCHW float tensor -> (3, B, C, H, W) float, pooled (B, C); H, W of the OUTPUT planes."""
+    lib = L.lib()
+    B, Cc, Hs, Ws = x_nchw.shape
+    H, W = Hs << ups, Ws << ups
+    xn = x_nchw.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    plan = C.c_void_p()
+    L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
+    ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda')
+    bands = [torch.empty(B, H, W, Cc, dtype=dtype, device='cuda') for _ in range(3)]
+    pooled = torch.empty(B, Cc, device='cuda')
+    L.check(lib.sr_fbm_lowpass(plan, L.dtype_code(dtype), B, L.view(xn), ups, L.view(bands[0]), L.view(bands[1]), L.view(bands[2]),
+                               pooled.data_ptr(), Cc, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    lib.sr_fbm_plan_destroy(plan)
+    return torch.stack([b.float().permute(0, 3, 1, 2) for b in bands]).cpu(), pooled.cpu()
+
+
+@pytest.mark.parametrize('hw', [(522, 532), (532, 522), (1044, 1064), (2088, 2128)])
+def test_lowpass_config3_window_sizes_fp32(sra, hw):
+    from super_resolution_amd import _lib as L
+    H, W = hw
+    x = torch.from_numpy(gp.signed_input((1, 2, H, W), 90))
+    got, pooled = _lowpass_gpu(L, x, torch.float32)
+    ref = fr.fbm_lowpass(x.double(), torch.float64)
+    err = (got.double() - ref).abs().max().item()
+    print('low-pass %dx%d fp32: max err %.3e' % (H, W, err))
+    assert err < 2e-5
+    assert (pooled.double() - x.double().mean(dim=(2, 3))).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('hw', [(1044, 1064), (2088, 2128)])
+def test_lowpass_config3_upsampled_source(sra, hw):
+    """conv_up1 / conv_up2 inputs: the planes of nearest2x(x) computed from the half-resolution source (ups = 1)."""
+    from super_resolution_amd import _lib as L
+    H, W = hw
+    x = torch.from_numpy(gp.signed_input((1, 2, H // 2, W // 2), 91))
+    got, pooled = _lowpass_gpu(L, x, torch.float32, ups=1)
+    up = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    ref = fr.fbm_lowpass(up.double(), torch.float64)
+    err = (got.double() - ref).abs().max().item()
+    print('low-pass of nearest2x -> %dx%d fp32: max err %.3e' % (H, W, err))
+    assert err < 2e-5
+    assert (pooled.double() - x.double().mean(dim=(2, 3))).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('hw', [(522, 532), (532, 532), (522, 522), (1044, 1064)])
+def test_lowpass_config3_window_sizes_bf16(sra, hw):
+    """bf16 trunk tensors (32-channel blocks) at the window sizes: whatever kernel family serves them, the planes must
+    match the fp64 oracle of the bf16-rounded input to bf16 rounding."""
+    from super_resolution_amd import _lib as L
+    H, W = hw
+    x = torch.from_numpy(gp.signed_input((2, 32, H, W), 92)).to(torch.bfloat16).float()
+    got, pooled = _lowpass_gpu(L, x, torch.bfloat16)
+    ref = fr.fbm_lowpass(x.double(), torch.float64)
+    err = (got.double() - ref).abs().max().item()
+    print('low-pass %dx%d bf16: max err %.3e' % (H, W, err))
+    assert err < 3 * 2.0 ** -8
+    assert (pooled.double() - x.double().mean(dim=(2, 3))).abs().max().item() < 2e-4
+
+
+@pytest.mark.timeout(600)
+def test_realesrganer_config3_windows_fdconv_vs_oracle(sra):
+    """RealESRGANer(tile=512, tile_pad=10) on a 1536 x 1536 RGB image: nine tiles with 522- and 532-pixel windows through
+    a 1-block RRDBNet-FDConv(3,3) in fp32; two of them (532 x 532 and 522 x 532) are checked against the oracle run on
+    the same window (tile-by-tile parity: FDConv's statistics are per window)."""
+    sd = t(gp.rrdbnet_state(3, 3, 64, 1, 32, seed=31))
+    net = sra.replace_conv_with_fdconv(sra.RRDBNet(3, 3, 4, 64, 1, 32))
+    net.load_state_dict(sd, strict=True)
+    img = gp.image_input((1536, 1536, 3), 93)
+    r = sra.RealESRGANer(scale=4, model_path=None, model=net, tile=512, tile_pad=10, pre_pad=0, half=False)
+    r.pre_process(img)
+    r.tile_process()
+    out = r.post_process()
+    assert out.shape == (1, 3, 6144, 6144)
+    wins = r.tile_windows()
+    sizes = sorted({(w[0][1] - w[0][0], w[0][3] - w[0][2]) for w in wins})
+    assert sizes == [(522, 522), (522, 532), (532, 522), (532, 532)]
+    x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))[None]
+    for ti in (4, 1):  # centre tile: 532 x 532; top middle: 522 x 532
+        (py0, py1, px0, px1), (y0, y1, x0, x1), (oy, ox) = wins[ti]
+        with torch.no_grad():
+            ref = rrdbnet_forward(sd, x[:, :, py0:py1, px0:px1])
+        ref = ref[:, :, oy * 4:(oy + y1 - y0) * 4, ox * 4:(ox + x1 - x0) * 4]
+        got = out[:, :, y0 * 4:y1 * 4, x0 * 4:x1 * 4].cpu()
+        err = (got - ref).abs().max().item()
+        print('tile %d window %dx%d: max|gpu - oracle| = %.3e' % (ti, py1 - py0, px1 - px0, err))
+        assert err < FP32_TOL, (ti, err)
+
+
+def test_realesrganer_config3_windows_bf16_batched(sra):
+    """The same tiling in bf16 with tile_batch = 4 against one tile at a time (bitwise: every statistic is per sample),
+    and against the fp32 run (PSNR)."""
+    sd = t(gp.rrdbnet_state(3, 3, 64, 1, 32, seed=31))
+    img = gp.image_input((1034, 1546, 3), 94)
+    outs = {}
+    for tag, half, tb in (('fp32', False, 1), ('bf16', True, 1), ('bf16_b4', True, 4)):
+        net = sra.replace_conv_with_fdconv(sra.RRDBNet(3, 3, 4, 64, 1, 32))
+        net.load_state_dict(sd, strict=True)
+        r = sra.RealESRGANer(scale=4, model_path=None, model=net, tile=512, tile_pad=10, pre_pad=0, half=half, tile_batch=tb)
+        r.pre_process(img)
+        r.tile_process()
+        outs[tag] = r.post_process().float().cpu()
+    assert torch.equal(outs['bf16'], outs['bf16_b4'])
+    p = psnr(outs['bf16'], outs['fp32'])
+    print('config-3 windows, 1-block FDConv net: bf16 vs fp32 PSNR %.1f dB' % p)
+    assert p > 40.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gate accumulation outside nf = 64 / gc = 32, odd sizes in bf16, tile batching with dynamic weights
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('nf,gc', [(64, 16), (128, 32), (80, 32), (32, 48)])
+def test_bf16_network_other_widths_vs_oracle(sra, nf, gc):
+    sd = t(gp.rrdbnet_state(1, 1, nf, 1, gc, seed=40 + nf + gc))
+    net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, nf, 1, gc))
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().cuda()
+    x = torch.from_numpy(gp.image_input((2, 1, 32, 32), 95))
+    with torch.no_grad():
+        ref = rrdbnet_forward(sd, x)
+        y32 = net(x.cuda()).cpu()
+        yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
+    err = (y32 - ref).abs().max().item()
+    p = psnr(yb, ref)
+    print('nf=%d gc=%d: fp32 err %.3e, bf16 vs fp32 oracle PSNR %.1f dB' % (nf, gc, err, p))
+    assert err < FP32_TOL
+    assert p > 35.0
+
+
+def test_bf16_network_odd_size_vs_oracle(sra):
+    sd = t(gp.rrdbnet_state(1, 1, 64, 2, 32, seed=12))
+    net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 2, 32))
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().cuda()
+    x = torch.from_numpy(gp.image_input((1, 1, 45, 70), 96))
+    with torch.no_grad():
+        ref = rrdbnet_forward(sd, x)
+        yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
+    p = psnr(yb, ref)
+    print('2-block bf16 at 45x70: PSNR vs fp32 oracle %.1f dB' % p)
+    assert p > 35.0
+
+
+def test_tile_batching_with_dynamic_weights(sra):
+    """RealESRGANer tiling on a network with active FDConv layers: tile_batch > 1 equals one-by-one exactly."""
+    sd = t(gp.rrdbnet_state(3, 3, 64, 1, 32, seed=33))
+    img = gp.image_input((100, 132, 3), 97)
+    outs = []
+    for tb in (1, 3):
+        net = sra.replace_conv_with_fdconv(sra.RRDBNet(3, 3, 4, 64, 1, 32))
+        net.load_state_dict(sd, strict=True)
+        r = sra.RealESRGANer(scale=4, model_path=None, model=net, tile=48, tile_pad=8, pre_pad=0, half=False, tile_batch=tb)
+        r.pre_process(img)
+        r.tile_process()
+        outs.append(r.post_process().cpu())
+    assert torch.equal(outs[0], outs[1])
+    x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))[None]
+    wins = r.tile_windows()
+    (py0, py1, px0, px1), (y0, y1, x0, x1), (oy, ox) = wins[4]
+    with torch.no_grad():
+        ref = rrdbnet_forward(sd, x[:, :, py0:py1, px0:px1])[:, :, oy * 4:(oy + y1 - y0) * 4, ox * 4:(ox + x1 - x0) * 4]
+    assert (outs[0][:, :, y0 * 4:y1 * 4, x0 * 4:x1 * 4] - ref).abs().max().item() < FP32_TOL
+
+
+def test_train_mode_forward_refuses_to_run_without_autograd(sra):
+    net = sra.RRDBNet(3, 3, 4, 8, 1, 4).cuda()  # modules are born in train() mode
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 3, 8, 8, device='cuda'))
+    with torch.no_grad():
+        assert net(torch.zeros(1, 3, 8, 8, device='cuda')).shape == (1, 3, 32, 32)  # plain net, no_grad: same as eval
+
+
+def test_dni_and_checkpoint_containers(sra, tmp_path):
+    """RealESRGANer.dni (utils.py:77-86): w0 * a + w1 * b on every entry, loaded through the list form of model_path."""
+    a = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=50, fdconv=False))
+    b = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=51, fdconv=False))
+    pa, pb = str(tmp_path / 'a.pth'), str(tmp_path / 'b.pth')
+    torch.save({'params': a}, pa)
+    torch.save({'params': b}, pb)
+    r = sra.RealESRGANer(scale=4, model_path=[pa, pb], dni_weight=[0.3, 0.7], model=sra.RRDBNet(3, 3, 4, 8, 1, 4), half=False)
+    mixed = {k: 0.3 * a[k] + 0.7 * b[k] for k in a}
+    got = r.model.state_dict()
+    assert all(torch.allclose(got[k].cpu(), mixed[k], atol=1e-7) for k in mixed)
+    x = torch.from_numpy(gp.image_input((1, 3, 12, 10), 98))
+    with torch.no_grad():
+        assert (r.model(x.cuda()).cpu() - rrdbnet_forward(mixed, x)).abs().max().item() < 1e-5
