@@ -35,21 +35,28 @@ def num_blocks_of(sd):
     return max(idx) + 1 if idx else 0
 
 
-def rrdbnet_forward(sd, x, scale=4, training=False, dtype=None, gmaps=None):
-    """RRDBNet.forward from a flat state_dict.  x: (B,C,H,W)."""
+def rrdbnet_forward(sd, x, scale=4, training=False, dtype=None, gmaps=None, emulate_bf16=False):
+    """RRDBNet.forward from a flat state_dict.  x: (B,C,H,W).
+
+    emulate_bf16: every tensor the network stores between layers is rounded to bfloat16 (as any bf16 evaluation of the
+    network, e.g. the reference under autocast, must), arithmetic stays in `dtype`: the yardstick the bf16 GPU path
+    is compared with where the network itself amplifies rounding."""
     dtype = dtype or x.dtype
     x = x.to(dtype)
     gmaps = gmaps if gmaps is not None else {}
+    q = (lambda t: t.to(torch.bfloat16).to(dtype)) if emulate_bf16 else (lambda t: t)
+    x = q(x)
 
     def conv(name, t):
-        return fdconv_forward(t, sub_state(sd, name), gmap=gmaps.get(name), training=training, dtype=dtype)
+        return fdconv_forward(t, sub_state(sd, name), gmap=gmaps.get(name), training=training, dtype=dtype,
+                              emulate_bf16=emulate_bf16)
 
-    lrelu = lambda t: F.leaky_relu(t, 0.2)
+    lrelu = lambda t: q(F.leaky_relu(t, 0.2))
     if scale == 2:
         x = pixel_unshuffle(x, 2)
     elif scale == 1:
         x = pixel_unshuffle(x, 4)
-    feat = conv('conv_first', x)
+    feat = q(conv('conv_first', x))
     body = feat
     for i in range(num_blocks_of(sd)):
         blk_in = body
@@ -61,12 +68,11 @@ def rrdbnet_forward(sd, x, scale=4, training=False, dtype=None, gmaps=None):
             t3 = lrelu(conv(p + 'conv3', torch.cat((t0, t1, t2), 1)))
             t4 = lrelu(conv(p + 'conv4', torch.cat((t0, t1, t2, t3), 1)))
             t5 = conv(p + 'conv5', torch.cat((t0, t1, t2, t3, t4), 1))
-            body = t5 * 0.2 + t0
-        body = body * 0.2 + blk_in
-    feat = feat + conv('conv_body', body)
+            body = q(t5 * 0.2 + t0) if j < 3 else q((t5 * 0.2 + t0) * 0.2 + blk_in)
+    feat = q(feat + conv('conv_body', body))
     feat = lrelu(conv('conv_up1', F.interpolate(feat, scale_factor=2, mode='nearest')))
     feat = lrelu(conv('conv_up2', F.interpolate(feat, scale_factor=2, mode='nearest')))
-    return conv('conv_last', lrelu(conv('conv_hr', feat)))
+    return q(conv('conv_last', lrelu(conv('conv_hr', feat))))
 
 
 class RRDBNetRef(nn.Module):

