@@ -136,6 +136,17 @@ size_t sr_fbm_workspace_bytes(const sr_fbm_plan* plan, int B, int C);
 int sr_fbm_lowpass(const sr_fbm_plan* plan, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4, sr_view l8,
                    float* pooled, int pooled_ld, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same low-pass with NO allocation anywhere and no caller workspace.  No counterpart in the reference: it exists for
+ * callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * The intermediates of the passes live in a device array of SR_STATIC_SCRATCH_BYTES that the library holds on every
+ * GPU it runs on until the process ends; shapes whose sr_fbm_workspace_bytes exceed it return SR_ERR_WORKSPACE
+ * (64 MiB: e.g. 1 x 64 channels x 384 x 384 or 4 x 32 x 256 x 256).  Calls that overlap on one GPU share the array
+ * and race: issue them on one stream.  The plan must have been created beforehand (plan creation allocates). */
+#define SR_STATIC_SCRATCH_BYTES (64u << 20)
+size_t sr_fbm_static_scratch_bytes(void);
+int sr_fbm_lowpass_static(const sr_fbm_plan* plan, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4, sr_view l8,
+                          float* pooled, int pooled_ld, void* stream);
+
 /* ---- FBM gates (FDConv.py:460-461): g_k = 2*sigmoid(conv3x3(x; gate_w[k]) + gate_b[k]) ------
  * gates: float (B,H,W,4) = {g1,g2,g3,unused}. */
 int sr_fbm_gates(int dtype, int B, int H, int W, const sr_concat* in, const sr_layer_params* lp, float* gates,

@@ -59,6 +59,9 @@ _SIGS = {
     'sr_fbm_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'sr_fbm_lowpass': (C.c_int, [C.c_void_p, C.c_int, C.c_int, View, C.c_int, View, View, View, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_fbm_static_scratch_bytes': (C.c_size_t, []),
+    'sr_fbm_lowpass_static': (C.c_int, [C.c_void_p, C.c_int, C.c_int, View, C.c_int, View, View, View, C.c_void_p, C.c_int,
+                                        C.c_void_p]),
     'sr_fbm_gates': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.POINTER(LayerParams), C.c_void_p,
                                C.c_void_p]),
     'sr_fbm_gates_accumulate': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, C.c_int, C.POINTER(GateConsumer), C.c_void_p]),

@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+
 #include "common.h"
 
 #include "fbm_plan.h"
@@ -632,4 +634,42 @@ extern "C" int sr_fbm_lowpass(const sr_fbm_plan* pl, int dtype, int B, sr_view x
     const long npix = (long)pl->H * pl->W;
     return fbm_lowpass_launch(pl, dtype, B, to_view(x, ups ? npix / 4 : npix), ups ? 1 : 0, to_view(l2, npix),
                               to_view(l4, npix), to_view(l8, npix), pooled, pooled_ld, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- the one entry point that allocates nothing --------------------------------------------------------------------
+// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it):
+// sr_fbm_lowpass with its workspace (the FFT / DFT intermediates T, S, U_k or T1, Y_k between the passes) in a
+// file-scope device array instead of a caller buffer.  Each GPU holds its own copy of the array at its own address
+// until the process ends; the kernels take that address as the `ws` argument exactly as in sr_fbm_lowpass.  Every
+// intermediate is written by one pass before the next pass reads it, so nothing has to start at zero, but all calls
+// on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.
+static __device__ __align__(256) unsigned char sr_static_scratch[SR_STATIC_SCRATCH_BYTES];
+static void* g_static_scratch_ptr[16];  // per device: address of that device's copy of the array
+static std::mutex g_static_scratch_mutex;
+
+static int static_scratch_for_current_device(void** out) {
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return SR_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (!g_static_scratch_ptr[dev]) {
+        void* p = nullptr;  // in host code the array's name is a stand-in, not a device address: ask the runtime
+        SR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(sr_static_scratch)));
+        if (!p) return SR_ERR_HIP;
+        g_static_scratch_ptr[dev] = p;
+    }
+    *out = g_static_scratch_ptr[dev];
+    return SR_OK;
+}
+
+extern "C" size_t sr_fbm_static_scratch_bytes(void) { return SR_STATIC_SCRATCH_BYTES; }
+
+extern "C" int sr_fbm_lowpass_static(const sr_fbm_plan* pl, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4,
+                                     sr_view l8, float* pooled, int pooled_ld, void* stream) {
+    SR_REQUIRE(pl && B > 0 && x.C > 0);
+    if (sr_fbm_workspace_bytes(pl, B, x.C) > SR_STATIC_SCRATCH_BYTES) return SR_ERR_WORKSPACE;  // beyond the fixed maximum
+    void* ws = nullptr;
+    const int rc = static_scratch_for_current_device(&ws);
+    if (rc != SR_OK) return rc;
+    return sr_fbm_lowpass(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, SR_STATIC_SCRATCH_BYTES, stream);
 }
