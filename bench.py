@@ -308,6 +308,7 @@ def main():
     ap.add_argument('--tile-batch', type=int, default=8)
     ap.add_argument('--cpu-sample', type=int, default=208, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
+    ap.add_argument('--no-split-weights', action='store_true', help='A/B: plain bf16 dynamic weights instead of hi + lo pairs')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -325,6 +326,12 @@ def main():
     if world > 1:
         dist.barrier()
 
+    if os.environ.get('SR_BENCH_SPLIT_TWO_PASS'):
+        from super_resolution_amd import _lib
+        _lib.lib().sr_debug_split_two_pass(1)
+    if args.no_split_weights:
+        from super_resolution_amd import _lib
+        _lib.lib().sr_debug_split_weights(0)
     res = (run_tiled if args.config == 'tiled' else run_batch)(args, world, rank, dev, dist)
     if rank == 0:
         print(json.dumps(res))

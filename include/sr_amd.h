@@ -105,6 +105,7 @@ typedef struct {
     const float* gate_b[3];                   /* ....bias (1) */
     const float* loc_w;                       /* KSM_Local.conv.weight (cout*9,1,taps) */
     const float *ln_w, *ln_b;                 /* KSM_Local.norm.{weight,bias} (cin) */
+    int64_t wpacked_lo_off;                   /* plain: elements from wpacked to the low-order parts (0: none) */
 } sr_layer_params;
 
 const char* sr_strerror(int code);
@@ -118,8 +119,9 @@ int sr_pack_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int B
                  void* stream);
 int sr_unpack_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W,
                    void* stream);
-/* nn.Conv2d weight (cout,cin,3,3) f32 -> [9][cout][cin] in `dtype` (what the conv kernels read) */
-int sr_pack_conv_weight(const float* w, void* dst, int dtype, int cout, int cin, void* stream);
+/* nn.Conv2d weight (cout,cin,3,3) f32 -> [9][cout][cin] in `dtype` (what the conv kernels read); dst_lo (may be NULL)
+ * receives w - dst in the same layout (split weights, see sr_fdconv_weightgen) */
+int sr_pack_conv_weight(const float* w, void* dst, void* dst_lo, int dtype, int cout, int cin, void* stream);
 
 /* ---- FBM low-pass (FDConv.py:427-457: rfft2 -> 3 box masks -> irfft2) ----------------------
  * A plan holds the twiddles, the nearest-resized masks (F.interpolate at FDConv.py:446) and the
@@ -179,14 +181,19 @@ int sr_fdconv_basis(const float* dft_weight, const uint8_t* gmap, float alpha, i
 /* per-sample weights W_b = sa*ca*fa*hr*sum_g ka_g*basis_g (FDConv.py:644-652,692-697) from the
  * pooled means (B, pooled_ld) -> wdyn [B][9][cout][cin] in dtype. */
 int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, void* wdyn,
-                        void* stream);
+                        void* wdyn_lo, void* stream);
+/* wdyn_lo (may be NULL): the same layout, receives w - wdyn, i.e. the part of each weight that rounding to `dtype` lost.
+ * In bf16 the pair (wdyn, wdyn_lo) carries 16 significant bits; sr_conv3x3 multiplies by both when given w_lo_offset.
+ * Why: a rounding error in a weight is coherent over every pixel it touches, and through 349 stacked layers with
+ * data-dependent weights it -- not the bf16 activations -- dominated the bf16 output error. */
 
 /* ---- 3x3 convolution, stride 1, zero pad 1 (F.conv2d at FDConv.py:699 / nn.Conv2d.forward) ---
- * weights: [9][cout][cin] per sample; w_bstride = elements between samples (0: shared weights).
+ * weights: [9][cout][cin] per sample; w_bstride = elements between samples (0: shared weights);
+ * w_lo_offset != 0: weights + w_lo_offset holds the low-order parts of the same weights (see sr_fdconv_weightgen).
  * With in->bands the A operand is FBM(x) = g1*x + (g2-g1)*L2 + (g3-g2)*L4 + (1-g3)*L8
  * (FDConv.py:456-479) formed on the fly from `gates`.  out: (B,H,W,cout) view. */
 int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, const void* weights,
-               long w_bstride, int cout, const sr_epilogue* ep, sr_view out, void* stream);
+               long w_bstride, long w_lo_offset, int cout, const sr_epilogue* ep, sr_view out, void* stream);
 
 /* ---- whole network (RRDBNet.forward) ------------------------------------------------------- */
 typedef struct sr_rrdbnet sr_rrdbnet;

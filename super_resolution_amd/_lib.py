@@ -39,7 +39,7 @@ class LayerParams(C.Structure):
                 ('ch_w', C.c_void_p), ('ch_b', C.c_void_p), ('fl_w', C.c_void_p), ('fl_b', C.c_void_p),
                 ('sp_w', C.c_void_p), ('sp_b', C.c_void_p), ('kn_w', C.c_void_p), ('kn_b', C.c_void_p),
                 ('gate_w', C.c_void_p * 3), ('gate_b', C.c_void_p * 3),
-                ('loc_w', C.c_void_p), ('ln_w', C.c_void_p), ('ln_b', C.c_void_p)]
+                ('loc_w', C.c_void_p), ('ln_w', C.c_void_p), ('ln_b', C.c_void_p), ('wpacked_lo_off', C.c_int64)]
 
 
 class GateConsumer(C.Structure):
@@ -52,7 +52,7 @@ _SIGS = {
     'sr_version': (C.c_int, []),
     'sr_pack_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_unpack_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'sr_pack_conv_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_pack_conv_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_fbm_plan_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     'sr_fbm_plan_destroy': (None, [C.c_void_p]),
     'sr_fbm_masks_host': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -68,8 +68,8 @@ _SIGS = {
     'sr_fdconv_basis_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'sr_fdconv_basis': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
-    'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_void_p, C.c_void_p]),
-    'sr_conv3x3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, C.c_void_p, C.c_long,
+    'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_conv3x3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, C.c_void_p, C.c_long, C.c_long,
                              C.c_int, C.POINTER(Epilogue), View, C.c_void_p]),
     'sr_rrdbnet_create': (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
     'sr_rrdbnet_destroy': (None, [C.c_void_p]),
@@ -88,6 +88,8 @@ _SIGS = {
     'sr_debug_gates_no_direct': (None, [C.c_int]),
     'sr_debug_mfma_no_fold': (None, [C.c_int]),
     'sr_debug_force_generic_gates': (None, [C.c_int]),
+    'sr_debug_split_weights': (None, [C.c_int]),
+    'sr_debug_split_two_pass': (None, [C.c_int]),
 }
 
 # every symbol include/sr_amd.h declares (the debug hook is not part of the header)
@@ -155,3 +157,17 @@ def require_gpu(t, who):
     if not t.is_cuda:
         raise RuntimeError('%s runs on an MI355X through libsr_amd only; got a %s tensor (no CPU path exists)'
                            % (who, t.device))
+
+
+def pack_plain_weight(w, dtype, cout, cin):
+    """(packed tensor, lo offset in elements) of an nn.Conv2d weight for the conv kernels.  bf16 and a thin layer
+    (min(cin, cout) <= 16: conv_first / conv_last, bandwidth-bound whatever the arithmetic): the weights are kept as
+    hi + lo pairs -- the rounding error of a weight is coherent over the whole image and, at the first layer of a deep
+    network, cost 12 dB of bf16 output PSNR (finding 15).  Wide plain layers (a plain RRDBNet is bound by
+    the matrix cores) keep single bf16 weights."""
+    split = dtype == torch.bfloat16 and min(cin, cout) <= 16
+    n = 9 * cout * cin
+    wp = torch.empty((2 if split else 1) * n, dtype=dtype, device=w.device)
+    check(lib().sr_pack_conv_weight(w.contiguous().data_ptr(), wp.data_ptr(), wp.data_ptr() + n * wp.element_size() if split else None,
+                                    dtype_code(dtype), cout, cin, stream_ptr(w.device)), 'sr_pack_conv_weight')
+    return wp, (n if split else 0)

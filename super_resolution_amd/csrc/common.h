@@ -167,8 +167,9 @@ inline Epilogue to_epilogue(const sr_epilogue* e, long npix) {
 }
 
 // internal launchers shared with the network executor (same semantics as the extern "C" entry points)
+// w_lo_off != 0 (bf16 MFMA kernel only): weights + w_lo_off holds the low-order bf16 parts of the same weights
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* weights,
-                   long w_bstride, int cout, const Epilogue& ep, View out, hipStream_t st);
+                   long w_bstride, long w_lo_off, int cout, const Epilogue& ep, View out, hipStream_t st);
 
 int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8,
                        float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st);
@@ -196,6 +197,6 @@ struct GateConsList {
 
 int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, hipStream_t st);  // bf16; SR_NOT_ELIGIBLE
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,
-                     hipStream_t st);
+                     void* wdyn_lo, hipStream_t st);
 
 }  // namespace sr

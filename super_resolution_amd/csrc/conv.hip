@@ -41,8 +41,8 @@ constexpr int CCC = 8;   // channels per LDS stage
 
 template <typename T, int OT>
 __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, const float* __restrict__ gates,
-                                                       const T* __restrict__ wts, long w_bstride, int cin, int cout,
-                                                       Epilogue ep, View out) {
+                                                       const T* __restrict__ wts, long w_bstride, long w_lo_off, int cin,
+                                                       int cout, Epilogue ep, View out) {
     __shared__ float tile[CCC][CT + 2][CT + 3];
     __shared__ __attribute__((aligned(16))) float wsh[9][CCC][OT];
     const int tilesx = (W + CT - 1) / CT;
@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, 
             for (int it = threadIdx.x; it < 9 * nc * OT; it += blockDim.x) {
                 const int o = it % OT, c = (it / OT) % nc, tap = it / (OT * nc);
                 float wv = 0.f;
-                if (o0 + o < cout) wv = Elem<T>::ld(wb + ((long)tap * cout + o0 + o) * cin + in.cstart[s] + cc + c);
+                if (o0 + o < cout) {
+                    const long at = ((long)tap * cout + o0 + o) * cin + in.cstart[s] + cc + c;
+                    wv = Elem<T>::ld(wb + at);
+                    if (w_lo_off) wv += Elem<T>::ld(wb + w_lo_off + at);  // split weights: hi + lo
+                }
                 wsh[tap][c][o] = wv;
             }
             __syncthreads();
@@ -106,11 +110,11 @@ __global__ __launch_bounds__(256) void conv3x3_generic(Concat in, int H, int W, 
 }
 
 template <typename T>
-static int launch_generic(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
+static int launch_generic(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo,
                           int cout, const Epilogue& ep, View out, hipStream_t st) {
     const int tiles = cdiv(H, CT) * cdiv(W, CT);
 #define SR_GEN(OT)                                                                                                   \
-    conv3x3_generic<T, OT><<<dim3(tiles, B, cdiv(cout, OT)), 256, 0, st>>>(in, H, W, gates, (const T*)wts, wbs, in.ctot, \
+    conv3x3_generic<T, OT><<<dim3(tiles, B, cdiv(cout, OT)), 256, 0, st>>>(in, H, W, gates, (const T*)wts, wbs, wlo, in.ctot, \
                                                                           cout, ep, out)
     if (cout <= 4) SR_GEN(4);
     else if (cout <= 8) SR_GEN(8);
@@ -166,10 +170,34 @@ struct ChunkCursor {  // walks the virtual concat in 32-channel chunks
     int s, cc, kc;
 };
 
-template <int MT, bool BANDS>
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the wave's global loads
+// (s_waitcnt vmcnt(0)): at the barrier in the middle of a chunk that would empty the loaders' two-deep load pipeline
+// once more per chunk (measured: +20 % conv time).  The data handed over at that barrier is LDS data only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Where a chunk's weight slab comes from: sample base (+ low-order offset), first concat channel, first output channel.
+struct WRef {
+    const bf16_t* base;
+    int kc, o_blk;
+};
+
+// Stages one 32-channel chunk: the haloed pixel tile into lds_px and weight slabs into LDS.
+// Split weights: the per-sample weights are kept as two bf16 numbers, w = hi + lo (lo = bf16(w - hi)) -- the rounding of
+// the dynamic weights, an error that is coherent over the whole image, was the dominant bf16 error of a deep network
+// (finding 15) -- and the consumers multiply by both parts.
+//   SPLIT = 0: slab `whi` -> lds_wa, after the pixel rounds (the slab buffers alternate with the pixel stages).
+//   SPLIT = 1: (MT = 2: four slabs do not fit LDS) the consumers run every chunk twice, once per part, out of ONE pixel
+//              stage.  Slab buffers: lds_wa holds hi parts, lds_wb lo parts.  The low part of the PREVIOUS chunk
+//              (`wlo`) is written first, then comes the workgroup barrier that separates the consumers' hi and lo
+//              half-steps of that chunk (mid_barrier; skipped for the very first chunk), then the rest of the pixels
+//              and the high part of this chunk.
+//   SPLIT = 2: (MT = 1) both parts of THIS chunk (`whi`, `wlo`) go to lds_wa / lds_wb after the pixel rounds; the
+//              consumers issue two MFMAs per pixel fragment.  One barrier per chunk as without the split.
+template <int MT, bool BANDS, int SPLIT>
 __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor& cur, int b, int H, int W, int h0, int w0,
-                                            const float* __restrict__ gates, const bf16_t* __restrict__ wb, int cin,
-                                            int cout, int o_blk, char* lds_px, char* lds_w, int ltid) {
+                                            const float* __restrict__ gates, const WRef whi, const WRef wlo,
+                                            bool mid_barrier, int cin, int cout, char* lds_px, char* lds_wa, char* lds_wb,
+                                            int ltid) {
     const View vx = in.x[cur.s];
     const int Ws = W >> in.ups;
     const bf16_t* xb = (const bf16_t*)vx.p + (long)b * vx.bs;
@@ -183,24 +211,36 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
     const bf16_t* b4 = BANDS ? (const bf16_t*)v4.p + (long)b * v4.bs : nullptr;
     const bf16_t* b8 = BANDS ? (const bf16_t*)v8.p + (long)b * v8.bs : nullptr;
     const float4* gb = (const float4*)gates + (long)b * H * W;
-    // ---- weight slab: rows (tap, o) x 32 channels (L2-resident); issued first so that its latency hides behind
-    // the pixel rounds, written to LDS last
+    // ---- weight slabs: rows (tap, o) x 32 channels (L2-resident); issued first so that their latency hides behind
+    // the pixel rounds
     constexpr int WITEMS = 9 * MT * 32 * 4;
     constexpr int WG = (WITEMS + 255) / 256;
-    uint4 wv[WG];
+    auto wload = [&](const WRef& r, uint4 (&wv)[WG]) {
 #pragma unroll
-    for (int g = 0; g < WG; ++g) {
-        const int it = ltid + g * 256;
-        const int chunk = it & 3, row = it >> 2;
-        const int tap = row / (MT * 32), o = row - tap * (MT * 32);
-        const int tapc = min(tap, 8), oc = min(o_blk + o, cout - 1);
-        wv[g] = *(const uint4*)(wb + ((long)tapc * cout + oc) * cin + cur.kc + chunk * 8);
-        if (o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
-    }
+        for (int g = 0; g < WG; ++g) {
+            const int it = ltid + g * 256;
+            const int chunk = it & 3, row = it >> 2;
+            const int tap = row / (MT * 32), o = row - tap * (MT * 32);
+            const int tapc = min(tap, 8), oc = min(r.o_blk + o, cout - 1);
+            wv[g] = *(const uint4*)(r.base + ((long)tapc * cout + oc) * cin + r.kc + chunk * 8);
+            if (r.o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto wstore = [&](const uint4 (&wv)[WG], char* lds_w) {
+#pragma unroll
+        for (int g = 0; g < WG; ++g) {
+            const int it = ltid + g * 256;
+            if (it < WITEMS) *(uint4*)(lds_w + swz(it >> 2, it & 3)) = wv[g];
+        }
+    };
+    uint4 wv_lo[WG], wv_hi[WG];
+    if (SPLIT) wload(wlo, wv_lo);  // unconditional (SPLIT = 1: a valid dummy reference for the first chunk): no branch around loads
+    wload(whi, wv_hi);
     // Rounds of G items per thread, software-pipelined two deep: round r + 1 is in flight while round r is modulated
     // and written to LDS, so the memory pipe never runs dry between rounds (the loaders are the only waves of the CU
     // with global loads in flight, and they never store: the compiler can count their loads exactly).
     constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
+    constexpr int RA = ROUNDS / 2;  // rounds ahead of the mid barrier (SPLIT = 1)
     struct Batch {
         uint4 vx[G], a2[G], a4[G], a8[G];
         float4 gg[G];
@@ -251,8 +291,10 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
     };
     Batch bt0, bt1;
     issue(0, bt0);
+    if (SPLIT == 1 && mid_barrier) wstore(wv_lo, lds_wb);  // the consumers are in the hi half-step of the previous chunk
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
+        if (SPLIT == 1 && r == RA && mid_barrier) lds_barrier();  // lo part of the previous chunk is in place
         if (r + 1 < ROUNDS) {
             if (r & 1) issue(r + 1, bt0);
             else issue(r + 1, bt1);
@@ -260,12 +302,8 @@ __device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor&
         if (r & 1) consume(r, bt1);
         else consume(r, bt0);
     }
-    // ---- weight slab (fetched first, see above) ---------------------------------------------------------
-#pragma unroll
-    for (int g = 0; g < WG; ++g) {
-        const int it = ltid + g * 256;
-        if (it < WITEMS) *(uint4*)(lds_w + swz(it >> 2, it & 3)) = wv[g];
-    }
+    wstore(wv_hi, lds_wa);
+    if (SPLIT == 2) wstore(wv_lo, lds_wb);
 }
 
 __device__ __forceinline__ bool advance(const Concat& in, ChunkCursor& cur) {
@@ -308,13 +346,21 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
     return t;
 }
 
-template <int MT, bool BANDS>
+// SPLIT != 0: wts holds the high parts, wts + w_lo_off the low parts of the same [B][9][cout][cin] weights.
+// Barrier protocol (every wave executes the same number of workgroup barriers):
+//   SPLIT 0, 2: loaders  fill(chunk s) -> barrier_s          consumers  barrier_s -> multiply(chunk s)
+//   SPLIT 1   : loaders  [lo(s-1), pixels A] -> barrier_{2s-1} -> [pixels B, hi(s)] -> barrier_{2s}; after the last chunk
+//               lo(last) -> barrier;          consumers  barrier_{2s} -> hi(s) -> barrier_{2s+1} -> lo(s)
+// LDS: two pixel stages, then the slabs: SPLIT 0: [stage 0][stage 1]; SPLIT 1: [hi][lo]; SPLIT 2: [s0 hi][s0 lo][s1 hi][s1 lo].
+template <int MT, bool BANDS, int SPLIT>
 __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
-                                                         const bf16_t* __restrict__ wts, long w_bstride, int cin,
-                                                         int cout, Epilogue ep, View out, unsigned total) {
+                                                         const bf16_t* __restrict__ wts, long w_bstride, long w_lo_off,
+                                                         int cin, int cout, Epilogue ep, View out, unsigned total) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int STAGE = NPIX * 64 + 9 * MT * 32 * 64;  // pixel tile + weight slab
     constexpr int STAGE_PX = NPIX * 64;
+    constexpr int WSLAB = 9 * MT * 32 * 64;
+    char* const lds_wa = lds + 2 * STAGE_PX;
+    char* const lds_wb = lds_wa + WSLAB;
     const int tilesx = (W + MTW - 1) / MTW;
     const unsigned tiles = (unsigned)tilesx * ((H + MTH - 1) / MTH);
     const int tid = threadIdx.x;
@@ -331,26 +377,50 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         // ahead of the MFMA waves across tile boundaries, so a tile's first chunk streams in while the previous
         // tile is still being multiplied and written out.
         unsigned step = 0;
+        WRef prev{wts, 0, 0};
         for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
             const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
             const bf16_t* wb = wts + (long)t.b * w_bstride;
             ChunkCursor cur{0, 0, 0};
             for (int c = 0; c < nchunks; ++c) {
-                char* dst = lds + (step & 1) * STAGE;
-                stage_chunk<MT, BANDS>(in, cur, t.b, H, W, t.h0, t.w0, gates, wb, cin, cout, t.o_blk, dst, dst + STAGE_PX,
-                                       tid - 256);
+                const WRef whi{wb, cur.kc, t.o_blk};
+                char* px = lds + (step & 1) * STAGE_PX;
+                if (SPLIT == 1) {
+                    const WRef wlo{prev.base + w_lo_off, prev.kc, prev.o_blk};
+                    stage_chunk<MT, BANDS, 1>(in, cur, t.b, H, W, t.h0, t.w0, gates, whi, step ? wlo : whi, step != 0, cin,
+                                              cout, px, lds_wa, lds_wb, tid - 256);
+                } else if (SPLIT == 2) {
+                    const WRef wlo{wb + w_lo_off, cur.kc, t.o_blk};
+                    char* slab = lds_wa + (step & 1) * 2 * WSLAB;
+                    stage_chunk<MT, BANDS, 2>(in, cur, t.b, H, W, t.h0, t.w0, gates, whi, wlo, false, cin, cout, px, slab,
+                                              slab + WSLAB, tid - 256);
+                } else {
+                    stage_chunk<MT, BANDS, 0>(in, cur, t.b, H, W, t.h0, t.w0, gates, whi, whi, false, cin, cout, px,
+                                              (step & 1) ? lds_wb : lds_wa, nullptr, tid - 256);
+                }
+                prev = whi;
                 advance(in, cur);
-                __syncthreads();  // stage `step` is full; stage `step - 1` has been consumed
+                __syncthreads();  // pixel stage and (hi) slab of chunk `step` are in place
                 ++step;
             }
         }
-        __syncthreads();  // pairs with the consumers' barrier after the last chunk
+        if (SPLIT == 1) {  // low part of the very last chunk
+            constexpr int WITEMS = 9 * MT * 32 * 4;
+            const int ltid = tid - 256;
+            for (int it = ltid; it < WITEMS; it += 256) {
+                const int chunk = it & 3, row = it >> 2;
+                const int tap = row / (MT * 32), o = row - tap * (MT * 32);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (prev.o_blk + o < cout) v = *(const uint4*)(prev.base + w_lo_off + ((long)tap * cout + prev.o_blk + o) * cin + prev.kc + chunk * 8);
+                *(uint4*)(lds_wb + swz(row, chunk)) = v;
+            }
+            __syncthreads();
+        }
         return;
     }
     unsigned step = 0;
-    float* bias_lds = (float*)(lds + 2 * STAGE);  // [cout], zeros without a bias
+    float* bias_lds = (float*)(lds + 2 * STAGE_PX + (SPLIT == 2 ? 4 : 2) * WSLAB);  // [cout], zeros without a bias
     for (int i = tid; i < cout; i += 256) bias_lds[i] = ep.bias ? ep.bias[i] : 0.f;
-    __syncthreads();  // stage 0 is full
     for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
         const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
         const int b = t.b, o_blk = t.o_blk, h0 = t.h0, w0 = t.w0;
@@ -361,9 +431,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
-            const char* cur_px = lds + (step & 1) * STAGE;
-            const char* cur_w = cur_px + STAGE_PX;
+        auto multiply = [&](const char* cur_px, const char* cur_w, const char* cur_w2) {
             // dy stays a real loop: fully unrolled, the 36 swizzled pixel addresses are hoisted into registers and
             // (with 128 accumulators at MT = 2) spill; reloading spills inside this loop costs more than the few
             // address instructions per iteration
@@ -375,20 +443,39 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const int chunk = kk * 2 + hk;
-                    short8 af[MT];
+                    short8 af[MT], af2[MT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) af[m] = *(const short8*)(cur_w + swz(tap * (MT * 32) + m * 32 + r, chunk));
+                    for (int m = 0; m < MT; ++m) {
+                        const int wo = swz(tap * (MT * 32) + m * 32 + r, chunk);
+                        af[m] = *(const short8*)(cur_w + wo);
+                        if (SPLIT == 2) af2[m] = *(const short8*)(cur_w2 + wo);
+                    }
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         const int pi = (wave * 4 + n + dy) * PW + r + dx;
                         const short8 bf = *(const short8*)(cur_px + swz(pi, chunk));
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
+                        for (int m = 0; m < MT; ++m) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
+                            if (SPLIT == 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[m], bf, acc[m][n], 0, 0, 0);
+                        }
                     }
                 }
             }
-            __syncthreads();  // stage `step` consumed; stage `step + 1` is full
+        };
+        for (int c = 0; c < nchunks; ++c) {
+            const char* cur_px = lds + (step & 1) * STAGE_PX;
+            __syncthreads();  // chunk `step`: pixel stage and (hi) slab are in place; the previous chunk is consumed
+            if (SPLIT == 1) {
+                multiply(cur_px, lds_wa, nullptr);
+                lds_barrier();  // lo slab of this chunk is in place
+                multiply(cur_px, lds_wb, nullptr);
+            } else if (SPLIT == 2) {
+                const char* slab = lds_wa + (step & 1) * 2 * WSLAB;
+                multiply(cur_px, slab, slab + WSLAB);
+            } else {
+                multiply(cur_px, (step & 1) ? lds_wb : lds_wa, nullptr);
+            }
             ++step;
         }
         // ---- epilogue: lane (r, hk) holds, for pixel (h, w0 + r), channels 8q + 4hk + {0..3} of each 32-channel tile.
@@ -504,45 +591,50 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
     return true;
 }
 
-template <int MT, bool BANDS>
-static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, int cout,
+template <int MT, bool BANDS, int SPLIT>
+static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
-    const size_t ldsb = 2 * ((size_t)NPIX * 64 + 9ul * MT * 32 * 64) + (size_t)cout * sizeof(float);  // stages + bias
+    const size_t ldsb = 2 * (size_t)NPIX * 64 + (SPLIT == 2 ? 4 : 2) * 9ul * MT * 32 * 64 + (size_t)cout * sizeof(float);  // stages + slabs + bias
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
-    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS>);  // per device
+    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
     if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-    conv3x3_mfma_bf16<MT, BANDS><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, in.ctot, cout, ep, out, (unsigned)nblk);
+    conv3x3_mfma_bf16<MT, BANDS, SPLIT><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
 
 int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
+int g_split_two_pass = 0;  // A/B hook: two half-steps per chunk also where the fused form fits (MT = 1)
 
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
-                   int cout, const Epilogue& ep, View out, hipStream_t st) {
-    if (dtype == SR_F32) return launch_generic<float>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+                   long wlo, int cout, const Epilogue& ep, View out, hipStream_t st) {
+    if (dtype == SR_F32) return launch_generic<float>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
     if (!g_force_generic && mfma_eligible(in, cout, ep, out, wts, wbs)) {
         const bool two = (cout % 64 == 0);
-        if (in.bands)
-            return two ? launch_mfma<2, true>(B, H, W, in, gates, wts, wbs, cout, ep, out, st)
-                       : launch_mfma<1, true>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
-        return two ? launch_mfma<2, false>(B, H, W, in, gates, wts, wbs, cout, ep, out, st)
-                   : launch_mfma<1, false>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+        if (wlo % 8 != 0) return SR_ERR_ARG;
+#define SR_MFMA(MT, BANDS, SPLIT) launch_mfma<MT, BANDS, SPLIT>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
+        if (in.bands) {
+            if (wlo) return two ? SR_MFMA(2, true, 1) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
+            return two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
+        }
+        if (wlo) return two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);
+        return two ? SR_MFMA(2, false, 0) : SR_MFMA(1, false, 0);
+#undef SR_MFMA
     }
-    return launch_generic<bf16_t>(B, H, W, in, gates, wts, wbs, cout, ep, out, st);
+    return launch_generic<bf16_t>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
 }
 }  // namespace sr
 
 using namespace sr;
 
 extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, const void* weights,
-                          long w_bstride, int cout, const sr_epilogue* ep, sr_view out, void* stream) {
+                          long w_bstride, long w_lo_offset, int cout, const sr_epilogue* ep, sr_view out, void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && in && weights && cout > 0 && out.p);
-    SR_REQUIRE(B <= 65535 && w_bstride >= 0);
+    SR_REQUIRE(B <= 65535 && w_bstride >= 0 && w_lo_offset >= 0);
     SR_REQUIRE(!in->ups || (H % 2 == 0 && W % 2 == 0));
     const long npix = (long)H * W;
     Concat c;
@@ -554,8 +646,11 @@ extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, c
     Epilogue e = to_epilogue(ep, npix);
     SR_REQUIRE(!e.r1.p || e.r1.C == cout);
     SR_REQUIRE(!e.r2.p || e.r2.C == cout);
-    return conv3x3_launch(dtype, B, H, W, c, gates, weights, w_bstride, cout, e, to_view(out, npix), (hipStream_t)stream);
+    int rc2 = conv3x3_launch(dtype, B, H, W, c, gates, weights, w_bstride, w_lo_offset, cout, e, to_view(out, npix), (hipStream_t)stream);
+    return rc2;
 }
 
 // test hook (not part of the product API): 1 routes bf16 convs through the VALU kernel
 extern "C" void sr_debug_force_generic_conv(int on) { sr::g_force_generic = on; }
+
+extern "C" void sr_debug_split_two_pass(int on) { sr::g_split_two_pass = on; }

@@ -69,13 +69,16 @@ __global__ void unpack_nhwc_kernel(const TS* __restrict__ src, TD* __restrict__ 
 }
 
 template <typename TD>
-__global__ void pack_weight_kernel(const float* __restrict__ w, TD* __restrict__ dst, int cout, int cin) {
+__global__ void pack_weight_kernel(const float* __restrict__ w, TD* __restrict__ dst, TD* __restrict__ dst_lo, int cout,
+                                   int cin) {
     const int n = 9 * cout * cin;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int c = i % cin;
         int o = (i / cin) % cout;
         int tap = i / (cin * cout);
-        Elem<TD>::st(dst + i, w[((long)o * cin + c) * 9 + tap]);
+        const float v = w[((long)o * cin + c) * 9 + tap];
+        Elem<TD>::st(dst + i, v);
+        if (dst_lo) Elem<TD>::st(dst_lo + i, v - Elem<TD>::ld(dst + i));  // what rounding to TD lost (w = hi + lo)
     }
 }
 
@@ -134,14 +137,14 @@ extern "C" int sr_unpack_nhwc(const void* src, int sdt, void* dst, int ddt, int 
     return SR_OK;
 }
 
-extern "C" int sr_pack_conv_weight(const float* w, void* dst, int dtype, int cout, int cin, void* stream) {
+extern "C" int sr_pack_conv_weight(const float* w, void* dst, void* dst_lo, int dtype, int cout, int cin, void* stream) {
     SR_REQUIRE(w && dst && dtype_ok(dtype) && cout > 0 && cin > 0);
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for(9L * cout * cin);
     if (dtype == SR_F32)
-        pack_weight_kernel<float><<<g, 256, 0, st>>>(w, (float*)dst, cout, cin);
+        pack_weight_kernel<float><<<g, 256, 0, st>>>(w, (float*)dst, (float*)dst_lo, cout, cin);
     else
-        pack_weight_kernel<bf16_t><<<g, 256, 0, st>>>(w, (bf16_t*)dst, cout, cin);
+        pack_weight_kernel<bf16_t><<<g, 256, 0, st>>>(w, (bf16_t*)dst, (bf16_t*)dst_lo, cout, cin);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

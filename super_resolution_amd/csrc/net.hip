@@ -55,6 +55,8 @@ struct sr_rrdbnet {
 namespace {
 
 // profile groups: head = conv_up1 / conv_up2 / conv_hr / conv_last (the 2x / 4x resolution convs), lowpass_hr = their low-pass launches
+int g_split_weights = 1;  // bf16: dynamic weights as hi + lo pairs (test hook sr_debug_split_weights)
+
 enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4, G_HEAD = 5, G_LOWPASS_HR = 6, G_NGROUPS = 8 };
 
 struct Layout {
@@ -101,7 +103,7 @@ Layout make_layout(const sr_rrdbnet* net, int dtype, int B, int H, int W) {
         size_t wmax = 0;  // largest cout * cin over the layers (conv4 beats conv5 when num_grow_ch > num_feat)
         for (const sr_layer_params& lp : net->layers)
             if ((size_t)lp.cout * lp.cin > wmax) wmax = (size_t)lp.cout * lp.cin;
-        L.wdyn = carve((size_t)B * 9 * wmax * es);
+        L.wdyn = carve(2 * (size_t)B * 9 * wmax * es);  // high and low parts (bf16: w = hi + lo)
         L.fft = carve(fft_ws_need(net, B, H, W));
     }
     L.total = off;
@@ -206,7 +208,9 @@ struct Run {
             hipStream_t wgs = fork ? net->side : st;
             if (fork && (hipEventRecord(net->ev_fork, st) != hipSuccess || hipStreamWaitEvent(net->side, net->ev_fork, 0) != hipSuccess)) { rc = SR_ERR_HIP; return; }
             prof_begin(G_WGEN, wgs);
-            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn, wgs);
+            const long wlo = dtype == SR_BF16 && g_split_weights ? (long)B * 9 * lp.cout * lp.cin : 0;  // elements from hi to lo
+            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn,
+                                  wlo ? ws + L.wdyn + (size_t)wlo * es : nullptr, wgs);
             prof_end(wgs);
             if (rc != SR_OK) return;
             if (fork && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
@@ -240,12 +244,13 @@ struct Run {
             if (rc != SR_OK) return;
             if (fork && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(head ? G_HEAD : G_CONV);
-            rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, lp.cout, ep, out, st);
+            rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, wlo, lp.cout, ep, out, st);
             prof_end();
         } else {
             if (!lp.wpacked) { rc = SR_ERR_STATE; return; }
             prof_begin(head ? G_HEAD : G_CONV);
-            rc = conv3x3_launch(dtype, B, Hc, Wc, c, nullptr, lp.wpacked, 0, lp.cout, ep, out, st);
+            rc = conv3x3_launch(dtype, B, Hc, Wc, c, nullptr, lp.wpacked, 0, dtype == SR_BF16 && g_split_weights ? (long)lp.wpacked_lo_off : 0,
+                                lp.cout, ep, out, st);
             prof_end();
         }
     }
@@ -513,3 +518,6 @@ extern "C" int sr_rrdbnet_profile_read(sr_rrdbnet* n, float* ms8, long* launches
     }
     return SR_OK;
 }
+
+// test hook (A/B): 0 = plain bf16 dynamic weights, 1 = hi + lo pairs (default)
+extern "C" void sr_debug_split_weights(int on) { g_split_weights = on; }

@@ -67,7 +67,8 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 
 template <typename T>
 __global__ __launch_bounds__(256) void weightgen_kernel(const float* __restrict__ pooled, int pooled_ld,
-                                                        sr_layer_params lp, T* __restrict__ wdyn, int o_per_block) {
+                                                        sr_layer_params lp, T* __restrict__ wdyn, T* __restrict__ wdyn_lo,
+                                                        int o_per_block) {
     extern __shared__ float sh[];
     const int cin = lp.cin, cout = lp.cout, taps = lp.loc_taps;
     float* g = sh;              // [cin] pooled means
@@ -145,19 +146,21 @@ __global__ __launch_bounds__(256) void weightgen_kernel(const float* __restrict_
 #pragma unroll
         for (int q = 0; q < KN; ++q) ad += ka[q] * lp.basis[(((long)q * cout + o) * cin + ci) * 9 + tap];
         const float w = sa[tap] * ca[ci] * fa[o] * ad * hr;
-        Elem<T>::st(wdyn + b * bstride + ((long)tap * cout + o) * cin + ci, w);
+        const long at = b * bstride + ((long)tap * cout + o) * cin + ci;
+        Elem<T>::st(wdyn + at, w);
+        if (wdyn_lo) Elem<T>::st(wdyn_lo + at, w - Elem<T>::ld(wdyn + at));  // w = hi + lo, both in T (bf16: 16 significant bits)
     }
 }
 
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,
-                     hipStream_t st) {
+                     void* wdyn_lo, hipStream_t st) {
     const int opb = 8;
     dim3 grid(B, cdiv(lp.cout, opb));
     const size_t sh = (3 * lp.cin + lp.cout + ATT + 9 + KN + 2) * sizeof(float);
     if (dtype == SR_F32)
-        weightgen_kernel<float><<<grid, 256, sh, st>>>(pooled, pooled_ld, lp, (float*)wdyn, opb);
+        weightgen_kernel<float><<<grid, 256, sh, st>>>(pooled, pooled_ld, lp, (float*)wdyn, (float*)wdyn_lo, opb);
     else
-        weightgen_kernel<bf16_t><<<grid, 256, sh, st>>>(pooled, pooled_ld, lp, (bf16_t*)wdyn, opb);
+        weightgen_kernel<bf16_t><<<grid, 256, sh, st>>>(pooled, pooled_ld, lp, (bf16_t*)wdyn, (bf16_t*)wdyn_lo, opb);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -193,7 +196,7 @@ extern "C" int sr_fdconv_basis(const float* dft_weight, const uint8_t* gmap, flo
 }
 
 extern "C" int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp,
-                                   void* wdyn, void* stream) {
+                                   void* wdyn, void* wdyn_lo, void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && pooled && wdyn && layer_ok_active(lp) && pooled_ld >= lp->cin);
-    return weightgen_launch(dtype, B, pooled, pooled_ld, *lp, wdyn, (hipStream_t)stream);
+    return weightgen_launch(dtype, B, pooled, pooled_ld, *lp, wdyn, wdyn_lo, (hipStream_t)stream);
 }

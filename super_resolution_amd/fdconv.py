@@ -205,9 +205,8 @@ class FDConv(nn.Conv2d):
         lp.bias = f32(self.bias.data) if self.bias is not None else None
         if not self.fdconv_active:
             lp.active = 0
-            wp = torch.empty(9 * self.out_channels * self.in_channels, dtype=dtype, device=dev)
-            L.check(lib.sr_pack_conv_weight(f32(self.weight.data), wp.data_ptr(), L.dtype_code(dtype), self.out_channels,
-                                            self.in_channels, st), 'sr_pack_conv_weight')
+            f32(self.weight.data)
+            wp, lp.wpacked_lo_off = L.pack_plain_weight(self.weight.data, dtype, self.out_channels, self.in_channels)
             keep.append(wp)
             lp.wpacked = wp.data_ptr()
         else:
@@ -273,7 +272,8 @@ class FDConv(nn.Conv2d):
         ep = L.Epilogue()
         ep.bias = lp.bias
         if not self.fdconv_active:
-            L.check(lib.sr_conv3x3(code, B, H, W, C.byref(cc), None, lp.wpacked, 0, cout, C.byref(ep), L.view(yn), st), 'sr_conv3x3')
+            L.check(lib.sr_conv3x3(code, B, H, W, C.byref(cc), None, lp.wpacked, 0, lp.wpacked_lo_off, cout, C.byref(ep), L.view(yn), st),
+                    'sr_conv3x3')
         else:
             plan = self._plan(H, W)
             bands = [torch.empty_like(xn) for _ in range(3)]
@@ -283,14 +283,17 @@ class FDConv(nn.Conv2d):
                                        pooled.data_ptr(), cin, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass')
             gates = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
             L.check(lib.sr_fbm_gates(code, B, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st), 'sr_fbm_gates')
-            wdyn = torch.empty(B, 9, cout, cin, dtype=dt, device=dev)
-            L.check(lib.sr_fdconv_weightgen(code, B, pooled.data_ptr(), cin, C.byref(lp), wdyn.data_ptr(), st), 'sr_fdconv_weightgen')
+            # bf16: weights as hi + lo pairs (a rounded weight is an error coherent over the whole image)
+            split = dt == torch.bfloat16
+            wdyn = torch.empty(2 if split else 1, B, 9, cout, cin, dtype=dt, device=dev)
+            L.check(lib.sr_fdconv_weightgen(code, B, pooled.data_ptr(), cin, C.byref(lp), wdyn[0].data_ptr(),
+                                            wdyn[1].data_ptr() if split else None, st), 'sr_fdconv_weightgen')
             cc.bands = 1
             cc.l2[0], cc.l4[0], cc.l8[0] = L.view(bands[0]), L.view(bands[1]), L.view(bands[2])
-            L.check(lib.sr_conv3x3(code, B, H, W, C.byref(cc), gates.data_ptr(), wdyn.data_ptr(), 9 * cout * cin, cout,
-                                   C.byref(ep), L.view(yn), st), 'sr_conv3x3')
+            L.check(lib.sr_conv3x3(code, B, H, W, C.byref(cc), gates.data_ptr(), wdyn.data_ptr(), 9 * cout * cin,
+                                   B * 9 * cout * cin if split else 0, cout, C.byref(ep), L.view(yn), st), 'sr_conv3x3')
             if want is not None:
-                want.update(pooled=pooled, gates=gates, wdyn=wdyn, l2=bands[0], l4=bands[1], l8=bands[2])
+                want.update(pooled=pooled, gates=gates, wdyn=wdyn[0], l2=bands[0], l4=bands[1], l8=bands[2])
         y = torch.empty(B, cout, H, W, dtype=dt, device=dev)
         L.check(lib.sr_unpack_nhwc(yn.data_ptr(), code, y.data_ptr(), code, B, cout, H, W, st), 'sr_unpack_nhwc')
         return y

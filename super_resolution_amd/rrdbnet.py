@@ -210,9 +210,7 @@ def _plain_params(m, dtype):
         raise TypeError('parameters must stay float32 (set compute_dtype for bf16 compute)')
     lp = L.LayerParams()
     lp.cin, lp.cout, lp.active = m.in_channels, m.out_channels, 0
-    wp = torch.empty(9 * m.out_channels * m.in_channels, dtype=dtype, device=w.device)
-    L.check(L.lib().sr_pack_conv_weight(w.contiguous().data_ptr(), wp.data_ptr(), L.dtype_code(dtype), m.out_channels,
-                                        m.in_channels, L.stream_ptr(w.device)), 'sr_pack_conv_weight')
+    wp, lp.wpacked_lo_off = L.pack_plain_weight(w, dtype, m.out_channels, m.in_channels)
     lp.wpacked = wp.data_ptr()
     keep = [wp, w]
     if m.bias is not None:

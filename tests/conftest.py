@@ -19,3 +19,12 @@ def golden():
     d = os.path.join(ROOT, 'tests', 'golden')
     return {n: np.load(os.path.join(d, n + '.npz')) for n in
             ('fdconv_layers', 'group_maps', 'fbm_masks', 'rrdbnet_fdconv_1block', 'realesrganer')}
+
+
+@pytest.fixture(scope='session')
+def golden_r2():
+    """Round-2 fixtures (tests/golden/make_golden_r2.py): reference gradients, converter output, SRVGG outputs."""
+    import numpy as np
+    d = os.path.join(ROOT, 'tests', 'golden')
+    return {n: np.load(os.path.join(d, n + '.npz')) for n in
+            ('fdconv_train_grads', 'rrdbnet_train_step', 'convert_ref', 'srvgg', 'fdconv_layers_r2')}

@@ -216,3 +216,62 @@ def test_checkpoint_conversion_matches_fdconv_init(tmp_path):
     assert convert.main(['convert', str(src), str(dst)]) == 0
     back = torch.load(dst, map_location='cpu', weights_only=True)
     assert 'body.0.rdb1.conv5.dft_weight' in back['params']
+
+
+def test_lanczos4_resize_properties():
+    """cv2.INTER_LANCZOS4 restatement (utils.py:256-261): identity at equal size, constants preserved, a linear ramp
+    stays linear away from the replicated border, integer dtypes are rounded and saturated.  Parity unpinned (no cv2)."""
+    from super_resolution_amd.realesrganer import lanczos4_resize
+    rng = np.random.RandomState(4)
+    img = (rng.rand(23, 31, 3) * 255).astype(np.uint8)
+    assert np.array_equal(lanczos4_resize(img, 23, 31), img)
+    const = np.full((16, 20), 1234, np.uint16)
+    assert np.array_equal(lanczos4_resize(const, 40, 9), np.full((40, 9), 1234, np.uint16))
+    ramp = np.tile(np.arange(64, dtype=np.float32)[None, :], (8, 1))
+    up = lanczos4_resize(ramp, 8, 128)
+    want = (np.arange(128) + 0.5) * 0.5 - 0.5
+    assert np.abs(up[:, 16:112] - want[None, 16:112]).max() < 0.02  # windowed sinc: not exact on ramps
+    sat = lanczos4_resize(np.array([[0, 255] * 8] * 4, np.uint8), 4, 37)
+    assert sat.dtype == np.uint8 and sat.min() == 0 and sat.max() == 255
+    down = lanczos4_resize(img, 10, 12)
+    assert down.shape == (10, 12, 3)
+
+
+def test_prefetch_reader_and_io_consumer(tmp_path):
+    """PrefetchReader / IOConsumer (utils.py:266-313): images come back in order, BGR like cv2.imread; the consumer
+    writes what it is handed until it receives 'quit'."""
+    import queue
+    from super_resolution_amd.realesrganer import IOConsumer, PrefetchReader
+    rng = np.random.RandomState(6)
+    imgs = [(rng.rand(9 + i, 7, 3) * 255).astype(np.uint8) for i in range(5)]
+    paths = []
+    que = queue.Queue()
+    worker = IOConsumer(None, que, 0)
+    worker.start()
+    for i, im in enumerate(imgs):
+        p = str(tmp_path / ('im%d.%s' % (i, 'png' if i % 2 else 'npy')))
+        paths.append(p)
+        que.put({'output': im, 'save_path': p})
+    que.put('quit')
+    worker.join(30)
+    assert not worker.is_alive()
+    reader = PrefetchReader(paths, num_prefetch_queue=2)
+    reader.start()
+    got = list(reader)
+    assert len(got) == 5 and all(np.array_equal(a, b) for a, b in zip(got, imgs))
+
+
+def test_converter_matches_reference_converter(golden_r2):
+    """super_resolution_amd.convert against the output of the reference's own tools/convert_to_fdconv.py (fixture
+    tests/golden/convert_ref.npz): same spectrum, same skip rule for thin layers, same sorted-frequency table."""
+    from super_resolution_amd import convert
+    from super_resolution_amd.fdconv import get_fft2freq
+    g = golden_r2['convert_ref']
+    r = np.random.RandomState(500)
+    w2 = torch.from_numpy(r.standard_normal((64, 32, 3, 3)).astype(np.float32))
+    assert 'layer1.0.conv2.dft_weight' in list(g['keys']) and 'layer1.0.conv3.weight' in list(g['keys'])
+    d = convert.spatial_to_dft_weight(w2)
+    assert d.shape == g['layer1.0.conv2.dft_weight'].shape
+    assert np.abs(d.numpy() - g['layer1.0.conv2.dft_weight']).max() < 1e-6
+    coords, _ = get_fft2freq(96, 192, use_rfft=True)
+    assert np.array_equal(coords.numpy(), g['idx_96_97'])

@@ -218,8 +218,13 @@ def test_enhance_modes_vs_oracle(sra):
         ref, m2 = rr.enhance(oracle_net, img, 4, **{'tile_pad': 10, **kw})
         assert m == m2 == mode and out.shape == ref.shape and out.dtype == ref.dtype
         assert np.abs(out.astype(np.int64) - ref.astype(np.int64)).max() <= 1  # rounding of a 1e-5 float difference
-    with pytest.raises(NotImplementedError):
-        r.enhance(cases[0][0], outscale=2)
+    # outscale != scale: the 4x result resized with the Lanczos-4 restatement (utils.py:256-261; parity unpinned, no cv2)
+    from super_resolution_amd.realesrganer import lanczos4_resize
+    r = sra.RealESRGANer(scale=4, model_path=None, model=net, half=False, tile=0, pre_pad=2)
+    out4, _ = r.enhance(cases[0][0], outscale=4)
+    out2, _ = r.enhance(cases[0][0], outscale=2.5)
+    assert out2.shape == (22, 17, 3) and out2.dtype == np.uint8
+    assert np.array_equal(out2, lanczos4_resize(out4, 22, 17))
 
 
 def test_cpu_tensor_is_refused(sra):

@@ -349,7 +349,7 @@ def test_basis_and_weightgen(L, cin, cout):
         torch.einsum('bg,goiuv->boiuv', ka, ref_b) * hr
     wd = torch.empty(B, 9, cout, cin, device='cuda:0')
     pd = dev(pooled)
-    L.check(lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), wd.data_ptr(), st(L)))
+    L.check(lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), wd.data_ptr(), None, st(L)))
     got_w = wd.cpu().view(B, 3, 3, cout, cin).permute(0, 3, 4, 1, 2)
     assert (got_w - ref_w).abs().max().item() < 2e-6 * max(1.0, ref_w.abs().max().item())
 
@@ -397,7 +397,7 @@ def run_conv(L, dt, xs, w, bias=None, lrelu=0, r1=None, s1=0.0, r2=None, s2=0.0,
         gd = nhwc(g4)
     out = torch.full((B, H, W, cout), float('nan'), device='cuda:0', dtype=dt)
     L.check(lib.sr_conv3x3(L.dtype_code(dt), B, H, W, C.byref(cc), None if gd is None else gd.data_ptr(), wd.data_ptr(),
-                           9 * cout * w.shape[-3] if per_sample else 0, cout, C.byref(ep), L.view(out), st(L)))
+                           9 * cout * w.shape[-3] if per_sample else 0, 0, cout, C.byref(ep), L.view(out), st(L)))
     torch.cuda.synchronize()
     return nchw(out)
 
@@ -557,7 +557,7 @@ def test_conv_and_gates_channel_blocked_layout(L, cb):
     ep.lrelu = 1
     ep.r1, ep.s1 = L.blocked_view(r1b), 0.2
     out = torch.full((B, cout // cb, H, W, cb), float('nan'), device='cuda:0', dtype=torch.bfloat16)
-    L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, cout, C.byref(ep),
+    L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, 0, cout, C.byref(ep),
                            L.blocked_view(out), st(L)))
     torch.cuda.synchronize()
     ref = ref_conv([x], wt, lrelu=1, r1=r1, s1=0.2, bands=[bands], gates=g3, ups=1, per_sample=True)

@@ -95,20 +95,51 @@ def test_23_blocks_fp32_vs_oracle_perturbed_weights(sra):
 
 
 def test_23_blocks_bf16_psnr_delta_realistic_weights(sra):
-    """north_star's bf16 criterion at config depth: 23 blocks, 2 x 1 x 128 x 128 (trunk on the MFMA low-pass)."""
+    """north_star's bf16 criterion at config depth (23 blocks, trunk on the MFMA low-pass).
+
+    Finding of round 2 (finding 15): on this network ANY evaluation that rounds the per-sample weights to
+    bf16 -- the oracle with bf16 operands included -- ends 15-20 dB from the fp32 output, because a rounded weight is an
+    error coherent over the whole image and 349 data-dependent layers amplify it; bf16 activations alone cost 50 dB.
+    The conv therefore multiplies by the weights as hi + lo bf16 pairs.  Checked here: (1) the PSNR-delta criterion on
+    the range-normalised output, (2) the direct bf16-vs-fp32 PSNR, (3) that split weights are what buys it (A/B through
+    the debug hook), (4) parity with the oracle's own bf16-storage emulation (same rounding points, hi + lo weights)."""
+    from super_resolution_amd import _lib
+    import oracle.fdconv_ref as fr_mod
     net, sd = realistic_net(sra, (1, 1, 4, 64, 23, 32), seed=2)
-    x = torch.from_numpy(gp.image_input((2, 1, 128, 128), 83))
+    x = torch.from_numpy(gp.image_input((1, 1, 64, 64), 83))
+    real = fr_mod._bf16
+
+    def hilo(v):  # weights (5-D per-sample, 4-D 3x3 of the thin plain layers) keep hi + lo, everything else one bf16 rounding
+        if v.dim() == 5 or (v.dim() == 4 and v.shape[-1] == 3):
+            hi = real(v)
+            return hi + real(v - hi)
+        return real(v)
+
     with torch.no_grad():
         ref = rrdbnet_forward(sd, x)
+        fr_mod._bf16 = hilo
+        try:
+            emu = rrdbnet_forward(sd, x, emulate_bf16=True)
+        finally:
+            fr_mod._bf16 = real
         yb = net(x.cuda().to(torch.bfloat16)).float().cpu()
+        _lib.lib().sr_debug_split_weights(0)
+        try:
+            yb_plain = net(x.cuda().to(torch.bfloat16)).float().cpu()
+        finally:
+            _lib.lib().sr_debug_split_weights(1)
     target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
-    # random-init outputs are not in [0, 1]: normalise both by the fp32 output's own range before the PSNR
+    # random-init outputs are not in [0, 1]: normalise by the fp32 output's own range before the PSNR
     lo, hi = ref.min(), ref.max()
-    ref, yb = (ref - lo) / (hi - lo), (yb - lo) / (hi - lo)
-    p_ref, p_bf, p_direct = psnr(ref.clamp(0, 1), target), psnr(yb.clamp(0, 1), target), psnr(yb, ref)
-    print('23-block bf16: PSNR vs target fp32 oracle %.3f dB, bf16 GPU %.3f dB; bf16-vs-fp32 direct %.1f dB' % (p_ref, p_bf, p_direct))
+    n = lambda v: (v - lo) / (hi - lo)
+    p_ref, p_bf = psnr(n(ref).clamp(0, 1), target), psnr(n(yb).clamp(0, 1), target)
+    d_gpu, d_plain, d_emu = psnr(n(yb), n(ref)), psnr(n(yb_plain), n(ref)), psnr(n(emu), n(ref))
+    print('23-block bf16: PSNR vs target fp32 oracle %.3f dB, bf16 GPU %.3f dB; direct bf16-vs-fp32: GPU %.1f dB, GPU with plain '
+          'bf16 weights %.1f dB, oracle bf16-storage emulation %.1f dB' % (p_ref, p_bf, d_gpu, d_plain, d_emu))
     assert abs(p_ref - p_bf) <= PSNR_DELTA_DB
-    assert p_direct > 35.0
+    assert d_gpu > 40.0
+    assert d_gpu > d_plain + 10.0
+    assert d_gpu > d_emu - 3.0
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -80,7 +80,7 @@ def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
     ep.lrelu = 1
 
     def run():
-        L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, cout, C.byref(ep),
+        L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, 0, cout, C.byref(ep),
                                mk(out), st))
     t = timeit(run, reps)
     px = B * H * W
