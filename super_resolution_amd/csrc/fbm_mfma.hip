@@ -183,23 +183,27 @@ struct AnaArgs {
     int dst_m, dst_i;
     const h16* basis; // fragment-major [pad32(M)][K]
     int K, M, NB, CG, nitems;
+    int tile0;        // first basis tile of this launch (waves take tiles tile0 .. tile0 + 7; M > 256 takes two launches)
     float scale;
     float* pooled;    // plane mean = DC coefficient * pool_scale (analysis along H only)
     int pooled_ld;
     float pool_scale;
 };
 
-template <bool FROM_VIEW>
+// KS = k-steps of 16 (32: K <= 512, the power-of-two trunk; 34: K <= 544, the 522 / 532-pixel windows of a tiled image).
+template <bool FROM_VIEW, int KS>
 __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
-    constexpr int G = 2, ROWB = 128, KS = 32;
+    constexpr int G = 2, ROWB = 128;
+    constexpr int IMG = KS * 16 * ROWB;   // bytes of one staged image
+    constexpr int NR = (KS * 16 + 63) / 64;  // loader rows per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // M is a multiple of 32 (host).  Waves beyond the last basis tile repeat it (same values to the same addresses):
     // with no predicate around the stores their number per group is a constant, which lets the compiler wait for the
     // prefetched loads only (vmcnt = stores issued since) instead of draining the stores at the end of every group.
-    const int NT = a.M >> 5, nks = a.K >> 4;
-    const int tw = min(wave, NT - 1);
+    const int NT = a.M >> 5, nks = (a.K + 15) >> 4;
+    const int tw = min(a.tile0 + wave, NT - 1);
     half8 bq[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
     }
     const int gpb = (a.nitems + G - 1) / G, ngroups = a.NB * gpb;
     const int ch = tid & 7, r0 = tid >> 3, oct = ch & 3;  // loader: rows r0 + 64 i, 16-byte chunk ch (item ch >> 2)
-    auto fetch = [&](int grp, uint4 (&pre)[8]) {
+    auto fetch = [&](int grp, uint4 (&pre)[NR]) {
         const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
         const int item = min(i0 + (ch >> 2), a.nitems - 1);
         if (FROM_VIEW) {
@@ -220,19 +224,19 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
             const bf16_t* xb = (const bf16_t*)a.x.p + (long)b * a.x.bs;
             const unsigned rowpix = (unsigned)(item >> a.ups) * a.Ws;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int k = min(r0 + 64 * i, a.K - 1);
                 pre[i] = *(const uint4*)(xb + voff32(a.x, rowpix + (k >> a.ups), cg * 32 + oct * 8));
             }
         } else {
             const h16* sb = a.src + (long)bcg * a.src_b + (long)item * a.src_i + oct * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 64 * i, a.K - 1) * a.src_k);
+            for (int i = 0; i < NR; ++i) pre[i] = *(const uint4*)(sb + (long)min(r0 + 64 * i, a.K - 1) * a.src_k);
         }
     };
-    auto stash = [&](const uint4 (&pre)[8], char* img) {
+    auto stash = [&](const uint4 (&pre)[NR], char* img) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int row = r0 + 64 * i;
             if (row < a.K) *(uint4*)(img + img_off<G>(row, ch)) = FROM_VIEW ? bf16x8_to_h16x8(pre[i]) : pre[i];
         }
@@ -240,11 +244,11 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
 
     int grp = blockIdx.x;
     if (grp >= ngroups) return;
-    uint4 pre[8];
+    uint4 pre[NR];
     fetch(grp, pre);
-    // rows K .. 511 of both images stay zero for ever: the k loop below always runs its 32 steps (a branch per k-step
-    // costs a copy of the accumulators at every join), the basis registers of the missing steps are zero as well
-    for (int i = tid; i < 2 * IMG_B / 16; i += THREADS) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // rows K .. 16 KS - 1 of both images stay zero for ever: the k loop below always runs its KS steps (a branch per
+    // k-step costs a copy of the accumulators at every join), the basis registers of the missing steps are zero as well
+    for (int i = tid; i < 2 * IMG / 16; i += THREADS) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     stash(pre, lds);
     __syncthreads();
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
         const bool more = ngrp < ngroups;
         fetch(more ? ngrp : grp, pre);  // unconditional: a branch around a load drains the memory pipe at the join
         asm volatile("" ::: "memory");  // the loads stay ahead of this group's stores
-        const char* img = lds + (it & 1) * IMG_B;
+        const char* img = lds + (it & 1) * IMG;
         {
             const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
             f32x16 acc[G];
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
             // The next image is staged BEFORE this group's stores are issued: the wait for the prefetched loads then has
             // nothing younger than them in the memory pipe (the compiler cannot assume that loads return ahead of younger
             // stores, it would drain every store here), and the stores drain under the next group's matrix phase.
-            if (more) stash(pre, lds + ((it + 1) & 1) * IMG_B);
+            if (more) stash(pre, lds + ((it + 1) & 1) * IMG);
             asm volatile("" ::: "memory");
             if (a.pooled && i0 == 0 && wave == 0 && m == 0) {  // mean = <x, q_0 p_0> / sqrt(HW)
                 const int b = bcg / a.CG, cg = bcg - b * a.CG;
@@ -283,8 +287,9 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                uint4* d = (uint4*)(a.dst + (long)bcg * a.dst_b + (long)m * a.dst_m + (long)(i0 + g) * a.dst_i + hk * 16);
-                d[0] = lo[g];  // nitems is even (host): both items exist
+                // an item beyond the last one repeats it (the loader clamped the same way): same values, same address
+                uint4* d = (uint4*)(a.dst + (long)bcg * a.dst_b + (long)m * a.dst_m + (long)min(i0 + g, a.nitems - 1) * a.dst_i + hk * 16);
+                d[0] = lo[g];
                 d[1] = hi[g];
             }
         }
@@ -320,39 +325,45 @@ struct SynArgs {
     View out[3];        // !SHARED: bf16 planes, pixel = item * Wout + m
     int Wout;
     int nitems[3];      // valid items of band k (nested, nitems[0] the largest)
-    int M, NB, CG;
+    int M, NB, CG;      // M: output rows rounded up to whole basis tiles
+    int Mv;             // valid output rows (rows Mv .. M - 1 of the basis table repeat row Mv - 1 and store to its address)
+    int tile0;          // first basis tile of this launch (waves take tiles tile0 .. tile0 + 15; M > 512 takes two launches)
     const h16* basis;   // fragment-major [pad32(M)][16 * nks_tab]
     int nks_tab;
 };
 
 // SHARED = true: synthesis along H (one staged coefficient image per item group, mask weights through the window rows,
 // fp16 out);  false: synthesis along W (one image per band, bf16 views out).
-template <bool SHARED>
+// KS = k-steps of 16 (16: K <= 256; 17: K <= 272, the 522 / 532-pixel windows of a tiled image -- with the window image
+// that is exactly the 160 KiB of LDS).
+template <bool SHARED, int KS>
 __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
-    constexpr int G = 4, ROWB = 256, KS = 16;
+    constexpr int G = 4, ROWB = 256;
+    constexpr int IMG = KS * 16 * ROWB;        // bytes of one staged image
+    constexpr int NR = (KS * 16 + 31) / 32;    // loader rows per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* winimg = lds + 2 * IMG_B;
-    float2* wts = (float2*)(winimg + WIN_B);
+    char* winimg = lds + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // M is a multiple of 32 (host); tiles beyond the last one repeat it, items beyond the last one repeat it (the loader
     // clamps the same way): no predicate around the stores, see mf_analysis
     const int NT = a.M >> 5;
-    const int tj[2] = {min(2 * wave, NT - 1), min(2 * wave + 1, NT - 1)};
+    const int tj[2] = {min(a.tile0 + 2 * wave, NT - 1), min(a.tile0 + 2 * wave + 1, NT - 1)};
     half8 bq[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             bq[ks][j] = ks < a.nks_tab ? *(const half8*)(a.basis + ((size_t)(tj[j] * a.nks_tab + ks) * 64 + lane) * 8) : zero_h8();
-    if (SHARED) {
-        if (tid < 3 * WIN_ROWS) wts[tid] = a.win[tid];
-    }
+    // window weights (s, d) of this thread's window row (tid >> 4), one pair per band: kept in registers
+    float2 wts[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wts[k] = SHARED ? a.win[k * WIN_ROWS + (tid >> 4)] : make_float2(0.f, 0.f);
     // SHARED: the narrower bands exist for the first item groups only (3, 2 or 1 bands of work per group); with the sample
     // index fastest a workgroup's groups (grp = blockIdx + n * gridDim) are spread over the whole item range
     const int gpb = (a.nitems[0] + G - 1) / G, ngroups = a.NB * gpb;
     // loader: rows r0 + 32 i, 16-byte chunk ch (item ch >> 2); tl = fresh_tid()
-    auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[8]) {
+    auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[NR]) {
         const int ch = tl & 15, r0 = tl >> 4, oct = ch & 3;
         const int bcg = SHARED ? grp % a.NB : grp / gpb, i0 = (SHARED ? grp / a.NB : grp - bcg * gpb) * G;
         const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
@@ -361,26 +372,26 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                         (long)item * sel3(band, a.src_i[0], a.src_i[1], a.src_i[2]) + oct * 8;
         const int sk = sel3(band, a.src_k[0], a.src_k[1], a.src_k[2]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int k = min(r0 + 32 * i, K - 1);
             pre[i] = *(const uint4*)(SHARED ? sb + (long)k * sk : u_addr(sb, k, a.nitems[0]));
         }
     };
-    // all 256 rows are written (zeros from row K on): the k loop always runs its 16 steps -- a branch per k-step costs a
+    // all 16 KS rows are written (zeros from row K on): the k loop always runs its steps -- a branch per k-step costs a
     // copy of the accumulators at every join -- and the basis registers are shared by bands of different K
-    auto stash = [&](int tl, const uint4 (&pre)[8], char* img, int band) {
+    auto stash = [&](int tl, const uint4 (&pre)[NR], char* img, int band) {
         const int ch = tl & 15, r0 = tl >> 4;
         const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int row = r0 + 32 * i;
-            *(uint4*)(img + img_off<G>(row, ch)) = row < K ? pre[i] : make_uint4(0u, 0u, 0u, 0u);
+            if (row < KS * 16) *(uint4*)(img + img_off<G>(row, ch)) = row < K ? pre[i] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
 
     int grp = blockIdx.x, band = 0;
     if (grp >= ngroups) return;
-    uint4 pre[8];
+    uint4 pre[NR];
     fetch(tid, grp, 0, pre);
     stash(tid, pre, lds, 0);
     __syncthreads();
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
         const bool more = ngrp < ngroups;
         fetch(fresh_tid(wave), more ? ngrp : grp, more ? nband : band, pre);  // unconditional (see mf_analysis)
         asm volatile("" ::: "memory");
-        const char* img = lds + (it & 1) * IMG_B;
+        const char* img = lds + (it & 1) * IMG;
         const int bcg = SHARED ? grp % a.NB : grp / gpb, i0 = (SHARED ? grp / a.NB : grp - bcg * gpb) * G;
         const int b = bcg / a.CG, cg = bcg - b * a.CG;
         const int hk = lane >> 5;
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
             for (int k = 0; k < 3; ++k) {
                 const int r = tl >> 4, ch = tl & 15;
                 const int n = 16 * a.ksm[k] + r;
-                const float2 w = wts[k * WIN_ROWS + r];
+                const float2 w = sel3(k, wts[0], wts[1], wts[2]);
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (r < 16 * a.nwin[k] && n < a.K[0] && (w.x != 0.f || w.y != 0.f)) {
                     const uint4 own = *(const uint4*)(img + img_off<G>(n, ch));
@@ -440,11 +451,11 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                 auto store = [&](int g, int j, const uint4& lo, const uint4& hi) {
                     // SHARED: the staged items are those of band 0, a narrower band drops the ones it does not have
                     if (SHARED && i0 + g >= nit) return;
-                    const int ig = min(i0 + g, nit - 1), m = tj[j] * 32 + (lane & 31);
+                    const int ig = min(i0 + g, nit - 1), m = min(tj[j] * 32 + (lane & 31), a.Mv - 1);
                     uint4* d;
                     if (SHARED) {
                         d = (uint4*)(sel3(k, a.dst[0], a.dst[1], a.dst[2]) + (long)bcg * sel3(k, a.dst_b[0], a.dst_b[1], a.dst_b[2]) +
-                                     ((long)(ig >> 2) * a.M + m) * 128 + (ig & 3) * 32 + hk * 16);
+                                     ((long)(ig >> 2) * a.Mv + m) * 128 + (ig & 3) * 32 + hk * 16);
                     } else {
                         const View o = sel3(k, a.out[0], a.out[1], a.out[2]);
                         d = (uint4*)((bf16_t*)o.p + (long)b * o.bs + voff32(o, (unsigned)ig * a.Wout + m, cg * 32 + hk * 16));
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                     }
                     if (g == 1) {
                         // stage the next image before the first store of this group goes out (see mf_analysis)
-                        if (!staged && more) stash(fresh_tid(wave), pre, lds + ((it + 1) & 1) * IMG_B, nband);
+                        if (!staged && more) stash(fresh_tid(wave), pre, lds + ((it + 1) & 1) * IMG, nband);
                         staged = true;
                         asm volatile("" ::: "memory");
 #pragma unroll
@@ -672,14 +683,16 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     using namespace mf;
     pl->mf_ok = 0;
     const int H = pl->H, W = pl->W;
-    if (!pl->contiguous || H % 32 || W % 32 || H > 512 || W > 512 || H < 32 || W < 32) return SR_OK;
+    // any even size from 32 to 544 (tables are zero-padded to whole k-steps / basis tiles); multiples of 32 up to 512 take
+    // the narrower kernel instances, everything else (the 522 / 532-pixel windows of a tiled image) the wider ones
+    if (!pl->contiguous || H % 2 || W % 2 || H > 544 || W > 544 || H < 32 || W < 32) return SR_OK;
     // x axis: mask k keeps column frequencies 0 .. half[k] - 1, nested
     for (int k = 0; k < 3; ++k) {
         if (pl->half[k] < 1 || 2 * (pl->half[k] - 1) >= W) return SR_OK;
         if (k && pl->half[k] > pl->half[k - 1]) return SR_OK;
     }
     const int jw = 2 * pl->half[0];
-    if (jw > 256) return SR_OK;
+    if (jw > 272) return SR_OK;  // synthesis depth: 17 k-steps
     // y axis: symmetric / antisymmetric parts of each row mask
     std::vector<double> s(3 * (H / 2 + 1), 0.0), d(3 * (H / 2 + 1), 0.0);
     int fmax[3];
@@ -697,7 +710,7 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
         if (k && fmax[k] > fmax[k - 1]) return SR_OK;
     }
     const int nh = 2 * (fmax[0] + 1);
-    if (nh > 256) return SR_OK;
+    if (nh > 272) return SR_OK;
     // the kernels see both coefficient counts rounded up to whole basis tiles (the extra functions are zero)
     pl->mf_jw = pad_to(jw, 32);
     pl->mf_nh = pad_to(nh, 32);
@@ -723,13 +736,14 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
         }
         pl->mf_ksm[k] = ksm;
         pl->mf_nwin[k] = last < 0 ? 0 : (last >> 4) + 1;
-        if (ksm + pl->mf_nwin[k] > 16) return SR_OK;
+        if (ksm + pl->mf_nwin[k] > (pad_to(nh, 16) >> 4)) return SR_OK;
     }
-    pl->mf_ld_qw = pad_to(jw, 32);
-    pl->mf_ld_ph = pad_to(nh, 32);
+    pl->mf_ld_qw = pad_to(jw, 16);
+    pl->mf_ld_ph = pad_to(nh, 16);
+    const int W16 = pad_to(W, 16), H16 = pad_to(H, 16);  // k extents of the analysis tables (zero beyond W / H)
     const bool fold = W % 64 == 0 && jw <= 256;  // folded synthesis along W (mf_synthesis_wf)
     const size_t n_qwf = fold ? (size_t)(W / 64 + 1) * 16 * 64 * 8 : 0;
-    const size_t n_qwt = (size_t)pad_to(jw, 32) * W, n_qw = (size_t)pad_to(W, 32) * pl->mf_ld_qw, n_pht = (size_t)pad_to(nh, 32) * H,
+    const size_t n_qwt = (size_t)pad_to(jw, 32) * W16, n_qw = (size_t)pad_to(W, 32) * pl->mf_ld_qw, n_pht = (size_t)pad_to(nh, 32) * H16,
                  n_ph = (size_t)pad_to(H, 32) * pl->mf_ld_ph;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -740,18 +754,18 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     h16* qw = (h16*)&host[o_qw];
     h16* pht = (h16*)&host[o_pht];
     h16* ph = (h16*)&host[o_ph];
-    for (int j = 0; j < jw; ++j)
-        for (int w = 0; w < W; ++w) {
-            const double v = basis_val(j, w, W);
-            qwt[frag_index(j, w, W / 16)] = (h16)v;
-            qw[frag_index(w, j, pl->mf_ld_qw / 16)] = (h16)(4.0 * v);  // U is kept as U / 4
-        }
-    for (int n = 0; n < nh; ++n)
-        for (int h = 0; h < H; ++h) {
-            const double v = basis_val(n, h, H);
-            pht[frag_index(n, h, H / 16)] = (h16)v;
-            ph[frag_index(h, n, pl->mf_ld_ph / 16)] = (h16)(16.0 * v);  // S is kept as S / 64, U as U / 4
-        }
+    // synthesis tables: output rows beyond the last valid one (whole-tile padding) repeat it; the kernels store them to
+    // the last row's address (same values, same address: no predicate around the stores)
+    for (int j = 0; j < jw; ++j) {
+        for (int w = 0; w < W; ++w) qwt[frag_index(j, w, W16 / 16)] = (h16)basis_val(j, w, W);
+        for (int w = 0; w < pad_to(W, 32); ++w)
+            qw[frag_index(w, j, pl->mf_ld_qw / 16)] = (h16)(4.0 * basis_val(j, std::min(w, W - 1), W));  // U is kept as U / 4
+    }
+    for (int n = 0; n < nh; ++n) {
+        for (int h = 0; h < H; ++h) pht[frag_index(n, h, H16 / 16)] = (h16)basis_val(n, h, H);
+        for (int h = 0; h < pad_to(H, 32); ++h)
+            ph[frag_index(h, n, pl->mf_ld_ph / 16)] = (h16)(16.0 * basis_val(n, std::min(h, H - 1), H));  // S is kept as S / 64, U as U / 4
+    }
     memcpy(&host[o_win], win.data(), win.size() * sizeof(float));
     if (fold) {
         h16* qwf = (h16*)&host[o_qwf];
@@ -809,7 +823,11 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     U[2] = U[1] + (size_t)NB * usz[1];
     if ((size_t)((char*)(U[2] + (size_t)NB * usz[2]) - (char*)ws) > sr_fbm_workspace_bytes(pl, B, C)) return SR_NOT_ELIGIBLE;
     auto grid_for = [&](long items, int G) { return (int)std::min<long>((long)NB * ((items + G - 1) / G), g_mfma_cus); };
-    const int lds_ana = 2 * IMG_B, lds_syn = 2 * IMG_B + WIN_B + 3 * WIN_ROWS * (int)sizeof(float2);
+    const int jw_real = pl->mf_nw[0], nh_real = pl->mf_nhk[0];
+    // wide instances: K up to 544 in the analysis (34 k-steps), up to 272 in the synthesis (17 k-steps)
+    const bool wide_aw = W > 512, wide_ah = H > 512, wide_s = pl->mf_ld_qw > 256 || pl->mf_ld_ph > 256;
+    auto lds_ana = [](bool wide) { return 2 * (wide ? 34 : 32) * 16 * 128; };
+    const int lds_syn = 2 * (wide_s ? 17 : 16) * 16 * 256 + WIN_B;
 
     AnaArgs a1{};  // T = x Qw
     a1.x = x;
@@ -828,9 +846,17 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     // fp16 range of the intermediates: an orthonormal coefficient can reach sqrt(W) (sqrt(H W)) times the largest
     // activation, so T and U are kept as T / 4, U / 4 and S as S / 64 (no overflow below |x| ~ 8000; the epilogues saturate)
     a1.scale = 0.25f;
-    SR_LDS_ATTR(lds_ana, mf_analysis<true>);
-    mf_analysis<true><<<grid_for(H, 2), THREADS, lds_ana, st>>>(a1);
-    SR_LAUNCH_CHECK();
+    for (int t0 = 0; t0 < jw / 32; t0 += 8) {  // more than 8 basis tiles: the data is streamed once per 8 tiles
+        a1.tile0 = t0;
+        if (wide_aw) {
+            SR_LDS_ATTR(lds_ana(true), mf_analysis<true, 34>);
+            mf_analysis<true, 34><<<grid_for(H, 2), THREADS, lds_ana(true), st>>>(a1);
+        } else {
+            SR_LDS_ATTR(lds_ana(false), mf_analysis<true, 32>);
+            mf_analysis<true, 32><<<grid_for(H, 2), THREADS, lds_ana(false), st>>>(a1);
+        }
+        SR_LAUNCH_CHECK();
+    }
 
     AnaArgs a2{};  // S = Ph^T T / 16
     a2.src = T;
@@ -846,14 +872,22 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     a2.M = nh;
     a2.NB = NB;
     a2.CG = CG;
-    a2.nitems = jw;
+    a2.nitems = jw_real + (jw_real & 1);
     a2.scale = 1.0f / 16.0f;
-    a2.pooled = pooled;
-    a2.pooled_ld = pooled_ld;
     a2.pool_scale = 4.0f / std::sqrt((float)H * (float)W);
-    SR_LDS_ATTR(lds_ana, mf_analysis<false>);
-    mf_analysis<false><<<grid_for(jw, 2), THREADS, lds_ana, st>>>(a2);
-    SR_LAUNCH_CHECK();
+    for (int t0 = 0; t0 < nh / 32; t0 += 8) {
+        a2.tile0 = t0;
+        a2.pooled = t0 == 0 ? pooled : nullptr;
+        a2.pooled_ld = pooled_ld;
+        if (wide_ah) {
+            SR_LDS_ATTR(lds_ana(true), mf_analysis<false, 34>);
+            mf_analysis<false, 34><<<grid_for(a2.nitems, 2), THREADS, lds_ana(true), st>>>(a2);
+        } else {
+            SR_LDS_ATTR(lds_ana(false), mf_analysis<false, 32>);
+            mf_analysis<false, 32><<<grid_for(a2.nitems, 2), THREADS, lds_ana(false), st>>>(a2);
+        }
+        SR_LAUNCH_CHECK();
+    }
 
     SynArgs s3{};  // U_k = P (weights_k S)
     for (int k = 0; k < 3; ++k) {
@@ -861,7 +895,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s3.src_b[k] = (long)nh * jw * 32;
         s3.src_k[k] = jw * 32;
         s3.src_i[k] = 32;
-        s3.K[k] = nh;
+        s3.K[k] = nh_real;
         s3.ksm[k] = pl->mf_ksm[k];
         s3.nwin[k] = pl->mf_nwin[k];
         s3.dst[k] = U[k];
@@ -871,14 +905,23 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s3.nitems[k] = pl->mf_nw[k];
     }
     s3.win = (const float2*)pl->mf_win;
-    s3.M = H;
+    s3.M = pad_to(H, 32);
+    s3.Mv = H;
     s3.NB = NB;
     s3.CG = CG;
     s3.basis = (const h16*)pl->mf_ph;
     s3.nks_tab = pl->mf_ld_ph / 16;
-    SR_LDS_ATTR(lds_syn, mf_synthesis<true>);
-    mf_synthesis<true><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
-    SR_LAUNCH_CHECK();
+    for (int t0 = 0; t0 < s3.M / 32; t0 += 16) {  // more than 16 basis tiles: S is streamed once per 16 tiles
+        s3.tile0 = t0;
+        if (wide_s) {
+            SR_LDS_ATTR(lds_syn, mf_synthesis<true, 17>);
+            mf_synthesis<true, 17><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
+        } else {
+            SR_LDS_ATTR(lds_syn, mf_synthesis<true, 16>);
+            mf_synthesis<true, 16><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
+        }
+        SR_LAUNCH_CHECK();
+    }
 
     SynArgs s4{};  // L_k = U_k Qw_k^T
     const View outs[3] = {l2, l4, l8};
@@ -893,7 +936,8 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s4.nitems[k] = H;
     }
     s4.Wout = W;
-    s4.M = W;
+    s4.M = pad_to(W, 32);
+    s4.Mv = W;
     s4.NB = NB;
     s4.CG = CG;
     if (pl->mf_qwf && !g_mfma_no_fold) {
@@ -902,13 +946,22 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s4.nks_tab = 16;
         SR_LDS_ATTR(2 * IMG_B, mf_synthesis_wf);
         mf_synthesis_wf<<<grid_for(H, 4), THREADS, 2 * IMG_B, st>>>(s4);
+        SR_LAUNCH_CHECK();
     } else {
         s4.basis = (const h16*)pl->mf_qw;
         s4.nks_tab = pl->mf_ld_qw / 16;
-        SR_LDS_ATTR(lds_syn, mf_synthesis<false>);
-        mf_synthesis<false><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
+        for (int t0 = 0; t0 < s4.M / 32; t0 += 16) {
+            s4.tile0 = t0;
+            if (wide_s) {
+                SR_LDS_ATTR(lds_syn, mf_synthesis<false, 17>);
+                mf_synthesis<false, 17><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
+            } else {
+                SR_LDS_ATTR(lds_syn, mf_synthesis<false, 16>);
+                mf_synthesis<false, 16><<<grid_for(H, 4), THREADS, lds_syn, st>>>(s4);
+            }
+            SR_LAUNCH_CHECK();
+        }
     }
-    SR_LAUNCH_CHECK();
     return SR_OK;
 }
 }  // namespace sr

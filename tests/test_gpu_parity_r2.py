@@ -191,7 +191,7 @@ def test_lowpass_config3_upsampled_source(sra, hw):
     assert (pooled.double() - x.double().mean(dim=(2, 3))).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize('hw', [(522, 532), (532, 532), (522, 522), (1044, 1064)])
+@pytest.mark.parametrize('hw', [(522, 532), (532, 532), (522, 522), (1044, 1064), (96, 80), (130, 78), (544, 34), (38, 540), (512, 530)])
 def test_lowpass_config3_window_sizes_bf16(sra, hw):
     """bf16 trunk tensors (32-channel blocks) at the window sizes: whatever kernel family serves them, the planes must
     match the fp64 oracle of the bf16-rounded input to bf16 rounding."""
