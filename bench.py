@@ -294,12 +294,69 @@ def run_tiled(args, world, rank, dev, dist):
     return res
 
 
+def run_srvgg(args, world, rank, dev, dist):
+    """BASELINE.json configs[4]: realesr-animevideov3's SRVGGNetCompact(3,3,64,16,4,'prelu') on 1080p frames, bf16."""
+    import golden_params as gp
+    from super_resolution_amd import SRVGGNetCompact
+    net = SRVGGNetCompact(3, 3, 64, 16, 4, 'prelu')
+    sd = {k: torch.from_numpy(v) for k, v in gp.srvgg_state(3, 3, 64, 16, 4, seed=600).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().to(dev)
+    B, H, W = args.frames, 1080, 1920
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev).to(torch.bfloat16)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            y = net(x)
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()  # the kernels are enqueued on torch's current stream: these events bracket them on that stream
+        for _ in range(args.steps):
+            y = net(x)
+        e1.record()
+        sync()
+        elapsed = time.perf_counter() - t0
+    kern_s = e0.elapsed_time(e1) / 1e3 / args.steps
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+    step_s = elapsed / args.steps
+    macs_px = 9 * (3 * 64 + 16 * 64 * 64 + 64 * 48)  # 619,200 MAC per LR pixel (SURVEY 8f-1)
+    flops = 2.0 * macs_px * B * H * W
+    strict_gb = B * H * W * (3 * ES + 17 * 2 * 64 * ES + 64 * ES + 48 * ES + 48 * ES + 3 * ES + 48 * ES) / 1e9
+    res = {
+        'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
+        'value': world * B * 16 * H * W / 1e6 / step_s, 'unit': 'output Mpix/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': max(args.warmup, 1), 'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': "SRVGGNetCompact(3,3,64,16,4,'prelu') x4 on %d synthetic 1920x1080 frames per step and GPU, bf16 "
+                               '(BASELINE.json configs[4])' % B,
+                   'frames_per_s': world * B / step_s,
+                   'published_reference': '10.0 fps on V100 (Real-ESRGAN-master/docs/anime_comparisons.md:60); other hardware',
+                   'output_finite': bool(torch.isfinite(y.float()).all())},
+        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_bf16 (18 conv launches per step)', 'achieved': flops / kern_s / 1e12,
+                     'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / kern_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                     'traffic': None,
+                     'hbm': {'achieved': strict_gb / kern_s, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': strict_gb / kern_s / HBM_PEAK_GBS}},
+    }
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', choices=('batch', 'tiled'), default='batch')
+    ap.add_argument('--config', choices=('batch', 'tiled', 'srvgg'), default='batch')
+    ap.add_argument('--frames', type=int, default=4, help='srvgg: 1080p frames per step')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')
@@ -332,7 +389,7 @@ def main():
     if args.no_split_weights:
         from super_resolution_amd import _lib
         _lib.lib().sr_debug_split_weights(0)
-    res = (run_tiled if args.config == 'tiled' else run_batch)(args, world, rank, dev, dist)
+    res = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch}[args.config](args, world, rank, dev, dist)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -71,8 +71,10 @@ typedef struct {
     sr_view l8[SR_MAX_SEG];
 } sr_concat;
 
-/* Epilogue of a conv:  y = acc + bias ; lrelu ? leaky_relu(y, 0.2) ; y = y*s1 + r1 ; y = y*s2 + r2
- * (RRDBNet: lrelu(conv(x)); ResidualDenseBlock x5*0.2+x; RRDB out*0.2+x; feat + body_feat). */
+/* Epilogue of a conv:  y = acc + bias ; activation ; y = y*s1 + r1 ; y = y*s2 + r2
+ * (RRDBNet: lrelu(conv(x)); ResidualDenseBlock x5*0.2+x; RRDB out*0.2+x; feat + body_feat).
+ * activation: slope != NULL: y < 0 ? slope[channel] * y : y  (nn.PReLU(num_parameters=cout) of SRVGGNetCompact,
+ * srvgg_arch.py:38,50; zeros give ReLU, a constant LeakyReLU); else lrelu ? leaky_relu(y, 0.2) : none. */
 typedef struct {
     const float* bias; /* [Cout] or NULL */
     int32_t lrelu;
@@ -83,6 +85,7 @@ typedef struct {
     sr_view r2;
     float s2;
     float _pad2;
+    const float* slope; /* [Cout] per-channel negative slopes or NULL */
 } sr_epilogue;
 
 /* Parameters of one conv layer of RRDBNet, as float32 device pointers straight into the
@@ -194,6 +197,25 @@ int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, co
  * (FDConv.py:456-479) formed on the fly from `gates`.  out: (B,H,W,cout) view. */
 int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, const void* weights,
                long w_bstride, long w_lo_offset, int cout, const sr_epilogue* ep, sr_view out, void* stream);
+
+/* ---- network ends (bandwidth-bound) ----------------------------------------------------------
+ * SRVGGNetCompact's tail (Real-ESRGAN-master/realesrgan/archs/srvgg_arch.py:65-68): dst (B,C,H*r,W*r) NCHW =
+ * nn.PixelShuffle(r)(src) + F.interpolate(base, scale_factor=r, mode='nearest'); src: (B,H,W,>=C*r*r) view in
+ * src_dtype (the last conv's output), base: the network input (B,C,H,W) NCHW in io_dtype. */
+int sr_pixel_shuffle_add(sr_view src, int src_dtype, const void* base, void* dst, int io_dtype, int B, int C, int H, int W,
+                         int r, void* stream);
+/* F.interpolate(x, size=(Hd,Wd), mode='bilinear', align_corners=False) on `planes` = B*C planes (NCHW)
+ * (train/train_realESRGAN_fdconv_1.py:115, train/test_realESRGAN_fdconv.py:51).  pre_sigmoid: nn.Sigmoid applied to the
+ * source first (CustomRRDBNet head, train/train_realESRGAN_fdconv.py:111-115); post_expm1: dst = max(expm1(v*post_scale), 0)
+ * (de-normalisation of train/test_realESRGAN_fdconv.py:55-57). */
+int sr_bilinear_resize(const void* src, int src_dtype, void* dst, int dst_dtype, long planes, int Hs, int Ws, int Hd, int Wd,
+                       int pre_sigmoid, int post_expm1, float post_scale, void* stream);
+/* loss = mean(w * |bilinear(act(pred), (Hd,Wd)) - target|): nn.L1Loss of fdconv_1.py:116 (weighted = 0) or the weighted L1
+ * of train_realESRGAN_fdconv.py:124-126 (w = clamp(10 * target, 0.1, 1)); float32.  loss: one float on the device.
+ * grad_pred (may be NULL): d loss / d pred, (planes,Hs,Ws), overwritten.  workspace: sr_resize_l1_workspace_bytes(). */
+size_t sr_resize_l1_workspace_bytes(void);
+int sr_resize_l1_loss(const float* pred, const float* target, long planes, int Hs, int Ws, int Hd, int Wd, int weighted,
+                      int pre_sigmoid, float* loss, float* grad_pred, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- whole network (RRDBNet.forward) ------------------------------------------------------- */
 typedef struct sr_rrdbnet sr_rrdbnet;

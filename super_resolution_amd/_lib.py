@@ -28,7 +28,7 @@ class Concat(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('lrelu', C.c_int32), ('_pad', C.c_int32),
                 ('r1', View), ('s1', C.c_float), ('_pad1', C.c_float),
-                ('r2', View), ('s2', C.c_float), ('_pad2', C.c_float)]
+                ('r2', View), ('s2', C.c_float), ('_pad2', C.c_float), ('slope', C.c_void_p)]
 
 
 class LayerParams(C.Structure):
@@ -71,6 +71,13 @@ _SIGS = {
     'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_conv3x3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, C.c_void_p, C.c_long, C.c_long,
                              C.c_int, C.POINTER(Epilogue), View, C.c_void_p]),
+    'sr_pixel_shuffle_add': (C.c_int, [View, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    'sr_bilinear_resize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'sr_resize_l1_workspace_bytes': (C.c_size_t, []),
+    'sr_resize_l1_loss': (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_rrdbnet_create': (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
     'sr_rrdbnet_destroy': (None, [C.c_void_p]),
     'sr_rrdbnet_num_layers': (C.c_int, [C.c_void_p]),

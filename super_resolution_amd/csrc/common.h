@@ -149,6 +149,7 @@ int to_concat(const sr_concat* in, long npix_x, long npix_bands, Concat* out);  
 
 struct Epilogue {
     const float* bias;
+    const float* slope;  // per-channel negative slopes (PReLU) or nullptr
     int lrelu;
     View r1, r2;
     float s1, s2;
@@ -158,6 +159,7 @@ inline Epilogue to_epilogue(const sr_epilogue* e, long npix) {
     if (e) {
         o.bias = e->bias;
         o.lrelu = e->lrelu;
+        o.slope = e->slope;
         o.r1 = to_view(e->r1, npix);
         o.r2 = to_view(e->r2, npix);
         o.s1 = e->s1;

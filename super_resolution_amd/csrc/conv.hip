@@ -27,7 +27,8 @@ __device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * 
 template <typename T>
 __device__ __forceinline__ float epilogue_one(float acc, int o, int b, long pix, const Epilogue& ep) {
     float y = acc + (ep.bias ? ep.bias[o] : 0.f);
-    if (ep.lrelu) y = lrelu02(y);
+    if (ep.slope) y = y > 0.f ? y : ep.slope[o] * y;
+    else if (ep.lrelu) y = lrelu02(y);
     if (ep.r1.p) y = y * ep.s1 + Elem<T>::ld((const T*)ep.r1.p + voff(ep.r1, b, pix, o));
     if (ep.r2.p) y = y * ep.s2 + Elem<T>::ld((const T*)ep.r2.p + voff(ep.r2, b, pix, o));
     return y;
@@ -420,7 +421,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
     }
     unsigned step = 0;
     float* bias_lds = (float*)(lds + 2 * STAGE_PX + (SPLIT == 2 ? 4 : 2) * WSLAB);  // [cout], zeros without a bias
-    for (int i = tid; i < cout; i += 256) bias_lds[i] = ep.bias ? ep.bias[i] : 0.f;
+    float* slope_lds = bias_lds + cout;  // [cout] negative slopes: PReLU's, 0.2 for LeakyReLU, 1 without activation
+    for (int i = tid; i < cout; i += 256) {
+        bias_lds[i] = ep.bias ? ep.bias[i] : 0.f;
+        slope_lds[i] = ep.slope ? ep.slope[i] : (ep.lrelu ? 0.2f : 1.0f);
+    }
     for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
         const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
         const int b = t.b, o_blk = t.o_blk, h0 = t.h0, w0 = t.w0;
@@ -511,10 +516,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 }
                 // bias (staged in LDS once per workgroup) + activation, written back over the accumulators
                 const float* bl = bias_lds + o_blk + m * 32 + hk * 16;
+                const float* sl = slope_lds + o_blk + m * 32 + hk * 16;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const float v = y[j] + bl[j];
-                    acc[m][n][j] = ep.lrelu ? lrelu02(v) : v;
+                    acc[m][n][j] = v > 0.f ? v : sl[j] * v;
                 }
             }
         }
@@ -594,7 +600,7 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
 template <int MT, bool BANDS, int SPLIT>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
-    const size_t ldsb = 2 * (size_t)NPIX * 64 + (SPLIT == 2 ? 4 : 2) * 9ul * MT * 32 * 64 + (size_t)cout * sizeof(float);  // stages + slabs + bias
+    const size_t ldsb = 2 * (size_t)NPIX * 64 + (SPLIT == 2 ? 4 : 2) * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
     SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);

@@ -1,0 +1,184 @@
+// Bandwidth-bound kernels around the networks' ends:
+//   sr_pixel_shuffle_add : SRVGGNetCompact's tail (srvgg_arch.py:65-68): nn.PixelShuffle(r) of the last conv's output plus
+//                          the nearest-upsampled input, NHWC -> NCHW.
+//   sr_bilinear_resize   : F.interpolate(pred, size, mode='bilinear', align_corners=False) of the owner scripts
+//                          (train/train_realESRGAN_fdconv_1.py:115, train/test_realESRGAN_fdconv.py:51) with the Sigmoid head
+//                          of CustomRRDBNet (train/train_realESRGAN_fdconv.py:111-115) folded in front and the expm1
+//                          de-normalisation of test_realESRGAN_fdconv.py:55-57 folded behind.
+//   sr_resize_l1_loss    : the training loss of the same scripts -- bilinear resize of the prediction to the target's size,
+//                          then nn.L1Loss (fdconv_1.py:116) or the weighted L1 of train_realESRGAN_fdconv.py:124-126 -- and
+//                          its gradient with respect to the prediction.
+#include "common.h"
+
+namespace sr {
+
+// torch's area_pixel_compute_source_index for align_corners = False: src = scale * (dst + 0.5) - 0.5, clamped at 0
+__device__ __forceinline__ void bilinear_taps(int d, float scale, int n_in, int& i0, int& i1, float& l1) {
+    float s = scale * ((float)d + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i0 = i0 > n_in - 1 ? n_in - 1 : i0;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename TS, typename TD>
+__global__ void pixel_shuffle_add_kernel(View src, const TD* __restrict__ base, TD* __restrict__ dst, int B, int C, int H, int W,
+                                         int r) {
+    const int Ho = H * r, Wo = W * r;
+    const long n = (long)B * C * Ho * Wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % Wo);
+        long t = i / Wo;
+        const int ho = (int)(t % Ho);
+        t /= Ho;
+        const int c = (int)(t % C), b = (int)(t / C);
+        const int h = ho / r, dy = ho - h * r, w = wo / r, dx = wo - w * r;
+        const float v = Elem<TS>::ld((const TS*)src.p + voff(src, b, (long)h * W + w, c * r * r + dy * r + dx));
+        const float x = Elem<TD>::ld(base + (((long)b * C + c) * H + h) * W + w);
+        Elem<TD>::st(dst + i, v + x);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void bilinear_resize_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long planes, int Hs, int Ws, int Hd,
+                                       int Wd, int pre_sigmoid, int post_expm1, float post_scale) {
+    const long n = planes * Hd * Wd;
+    const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wd);
+        long t = i / Wd;
+        const int y = (int)(t % Hd);
+        const long p = t / Hd;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_taps(y, sh, Hs, y0, y1, ly);
+        bilinear_taps(x, sw, Ws, x0, x1, lx);
+        const TS* s = src + p * Hs * Ws;
+        float a = Elem<TS>::ld(s + (long)y0 * Ws + x0), b = Elem<TS>::ld(s + (long)y0 * Ws + x1);
+        float c = Elem<TS>::ld(s + (long)y1 * Ws + x0), d = Elem<TS>::ld(s + (long)y1 * Ws + x1);
+        if (pre_sigmoid) { a = sigmoid_f(a); b = sigmoid_f(b); c = sigmoid_f(c); d = sigmoid_f(d); }
+        float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+        if (post_expm1) v = fmaxf(expm1f(v * post_scale), 0.f);
+        Elem<TD>::st(dst + i, v);
+    }
+}
+
+// one block reduces its grid-stride share; partial sums go to `partial[blockIdx]` (a second tiny kernel adds them in a
+// fixed order: the loss is deterministic).  grad (may be null): d loss / d pred, accumulated with float atomics.
+__global__ __launch_bounds__(256) void resize_l1_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        long planes, int Hs, int Ws, int Hd, int Wd, int weighted,
+                                                        int pre_sigmoid, float inv_n, float* __restrict__ partial,
+                                                        float* __restrict__ grad) {
+    __shared__ float red[256];
+    const long n = planes * Hd * Wd;
+    const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+    float acc = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wd);
+        long t = i / Wd;
+        const int y = (int)(t % Hd);
+        const long p = t / Hd;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_taps(y, sh, Hs, y0, y1, ly);
+        bilinear_taps(x, sw, Ws, x0, x1, lx);
+        const float* s = pred + p * Hs * Ws;
+        float a = s[(long)y0 * Ws + x0], b = s[(long)y0 * Ws + x1], c = s[(long)y1 * Ws + x0], d = s[(long)y1 * Ws + x1];
+        if (pre_sigmoid) { a = sigmoid_f(a); b = sigmoid_f(b); c = sigmoid_f(c); d = sigmoid_f(d); }
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        const float v = w00 * a + w01 * b + w10 * c + w11 * d;
+        const float tg = target[i];
+        const float wt = weighted ? fminf(fmaxf(tg * 10.f, 0.1f), 1.0f) : 1.0f;  // train_realESRGAN_fdconv.py:125
+        const float diff = v - tg;
+        acc += wt * fabsf(diff);
+        if (grad) {
+            const float g = wt * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * inv_n;  // torch: sign(0) = 0
+            float* gp = grad + p * Hs * Ws;
+            const float ga = pre_sigmoid ? a * (1.f - a) : 1.f, gb = pre_sigmoid ? b * (1.f - b) : 1.f;
+            const float gc = pre_sigmoid ? c * (1.f - c) : 1.f, gd = pre_sigmoid ? d * (1.f - d) : 1.f;
+            atomicAdd(gp + (long)y0 * Ws + x0, g * w00 * ga);
+            atomicAdd(gp + (long)y0 * Ws + x1, g * w01 * gb);
+            atomicAdd(gp + (long)y1 * Ws + x0, g * w10 * gc);
+            atomicAdd(gp + (long)y1 * Ws + x1, g * w11 * gd);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)partial[i];
+        *out = (float)(s * (double)scale);
+    }
+}
+
+static int head_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" int sr_pixel_shuffle_add(sr_view src, int src_dtype, const void* base, void* dst, int io_dtype, int B, int C,
+                                    int H, int W, int r, void* stream) {
+    SR_REQUIRE(src.p && base && dst && dtype_ok(src_dtype) && dtype_ok(io_dtype) && B > 0 && C > 0 && H > 0 && W > 0 && r >= 1);
+    SR_REQUIRE(src.C >= C * r * r && src.c0 >= 0 && view_block_ok(src));
+    const View v = to_view(src, (long)H * W);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid((long)B * C * H * W * r * r);
+#define SR_PS(TS, TD) pixel_shuffle_add_kernel<TS, TD><<<g, 256, 0, st>>>(v, (const TD*)base, (TD*)dst, B, C, H, W, r)
+    if (src_dtype == SR_F32 && io_dtype == SR_F32) SR_PS(float, float);
+    else if (src_dtype == SR_F32) SR_PS(float, bf16_t);
+    else if (io_dtype == SR_F32) SR_PS(bf16_t, float);
+    else SR_PS(bf16_t, bf16_t);
+#undef SR_PS
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_bilinear_resize(const void* src, int src_dtype, void* dst, int dst_dtype, long planes, int Hs, int Ws, int Hd,
+                                  int Wd, int pre_sigmoid, int post_expm1, float post_scale, void* stream) {
+    SR_REQUIRE(src && dst && dtype_ok(src_dtype) && dtype_ok(dst_dtype) && planes > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid(planes * Hd * Wd);
+#define SR_RS(TS, TD) \
+    bilinear_resize_kernel<TS, TD><<<g, 256, 0, st>>>((const TS*)src, (TD*)dst, planes, Hs, Ws, Hd, Wd, pre_sigmoid, post_expm1, post_scale)
+    if (src_dtype == SR_F32 && dst_dtype == SR_F32) SR_RS(float, float);
+    else if (src_dtype == SR_F32) SR_RS(float, bf16_t);
+    else if (dst_dtype == SR_F32) SR_RS(bf16_t, float);
+    else SR_RS(bf16_t, bf16_t);
+#undef SR_RS
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" size_t sr_resize_l1_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+extern "C" int sr_resize_l1_loss(const float* pred, const float* target, long planes, int Hs, int Ws, int Hd, int Wd, int weighted,
+                                 int pre_sigmoid, float* loss, float* grad_pred, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    SR_REQUIRE(pred && target && loss && workspace && planes > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0);
+    if (workspace_bytes < sr_resize_l1_workspace_bytes()) return SR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long n = planes * Hd * Wd;
+    int g = head_grid(n);
+    if (g > 1024) g = 1024;
+    if (grad_pred) SR_HIP(hipMemsetAsync(grad_pred, 0, (size_t)planes * Hs * Ws * sizeof(float), st));
+    resize_l1_kernel<<<g, 256, 0, st>>>(pred, target, planes, Hs, Ws, Hd, Wd, weighted, pre_sigmoid, 1.0f / (float)n,
+                                        (float*)workspace, grad_pred);
+    SR_LAUNCH_CHECK();
+    sum_partials_kernel<<<1, 64, 0, st>>>((const float*)workspace, g, 1.0f / (float)n, loss);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}

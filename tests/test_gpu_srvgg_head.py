@@ -1,0 +1,95 @@
+"""SRVGGNetCompact (BASELINE configs[4]) and the post-network head of the owner scripts (8f-4) on the GPU,
+against the reference's own outputs (tests/golden/srvgg.npz) and torch's CPU operators."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_params as gp
+from oracle.srvgg_ref import srvgg_forward
+
+pytestmark = pytest.mark.gpu
+
+CASES = (('anime', (3, 3, 64, 16, 4), 'prelu', (2, 3, 24, 20)), ('x2_relu', (3, 3, 32, 2, 2), 'relu', (1, 3, 17, 13)),
+         ('gray_leaky', (1, 1, 64, 3, 4), 'leakyrelu', (1, 1, 9, 33)))
+
+
+def t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize('tag,args,act,shape', CASES)
+def test_srvgg_vs_reference_golden(golden_r2, tag, args, act, shape):
+    from super_resolution_amd import SRVGGNetCompact
+    net = SRVGGNetCompact(*args, act_type=act)
+    assert len(net.state_dict()) == int(golden_r2['srvgg'][tag + '.n_keys'])
+    net.load_state_dict(t(gp.srvgg_state(*args, seed=600, act_type=act)), strict=True)
+    net = net.eval().cuda()
+    x = torch.from_numpy(gp.image_input(shape, seed=601))
+    with torch.no_grad():
+        y = net(x.cuda()).cpu().numpy()
+        yb = net(x.cuda().to(torch.bfloat16)).float().cpu().numpy()
+    ref = golden_r2['srvgg'][tag]
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-4
+    rel = np.abs(yb - ref).max() / np.abs(ref).max()
+    print('%s: fp32 err %.2e, bf16 rel err %.2e' % (tag, np.abs(y - ref).max(), rel))
+    assert rel < 3e-2
+
+
+def test_srvgg_1080p_frame_properties():
+    """BASELINE configs[4] at full size (1 x 3 x 1080 x 1920, bf16): the oracle is compared on a crop whose receptive field
+    (18 convs = 18 pixels) lies inside the frame; plus shape and batch independence."""
+    from super_resolution_amd import SRVGGNetCompact
+    sd = t(gp.srvgg_state(3, 3, 64, 16, 4, seed=600))
+    net = SRVGGNetCompact(3, 3, 64, 16, 4, 'prelu')
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().cuda()
+    x = torch.rand(2, 3, 1080, 1920, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        y = net(x.cuda().to(torch.bfloat16))
+        y1 = net(x[1:2].cuda().to(torch.bfloat16))
+    assert y.shape == (2, 3, 4320, 7680) and torch.equal(y[1:2], y1)
+    crop = x[0:1, :, 500:580, 900:1000].to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = srvgg_forward(sd, crop)
+    got = y[0:1, :, 2000 + 80:2320 - 80, 3600 + 80:4000 - 80].float().cpu()
+    want = ref[:, :, 80:-80, 80:-80]
+    assert (got - want).abs().max().item() < 3e-2 * want.abs().max().item()
+
+
+def test_bilinear_resize_matches_torch():
+    from super_resolution_amd import head
+    g = torch.Generator().manual_seed(5)
+    for (hs, ws), (hd, wd) in (((64, 64), (80, 80)), ((37, 53), (21, 90)), ((128, 128), (128, 128)), ((16, 20), (2048, 96))):
+        x = torch.randn(2, 3, hs, ws, generator=g)
+        got = head.bilinear_resize(x.cuda(), (hd, wd)).cpu()
+        ref = F.interpolate(x, size=(hd, wd), mode='bilinear', align_corners=False)
+        assert (got - ref).abs().max().item() < 2e-6, ((hs, ws), (hd, wd))
+    # Sigmoid head in front (train_realESRGAN_fdconv.py:111-115), expm1 de-normalisation behind (test_realESRGAN_fdconv.py:55-57)
+    x = torch.randn(1, 1, 40, 40, generator=g)
+    got = head.bilinear_resize(x.cuda(), (96, 96), sigmoid=True, expm1_scale=1.0).cpu()
+    ref = torch.clamp(torch.expm1(F.interpolate(torch.sigmoid(x), size=(96, 96), mode='bilinear', align_corners=False)), min=0)
+    assert (got - ref).abs().max().item() < 1e-5
+    xb = x.to(torch.bfloat16)
+    got = head.bilinear_resize(xb.cuda(), (96, 96), out_dtype=torch.float32).cpu()
+    assert (got - F.interpolate(xb.float(), size=(96, 96), mode='bilinear', align_corners=False)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('weighted,sigmoid', [(False, False), (True, True), (True, False)])
+def test_resize_l1_loss_and_gradient_match_torch(weighted, sigmoid):
+    from super_resolution_amd import head
+    g = torch.Generator().manual_seed(6)
+    pred = torch.randn(2, 1, 64, 64, generator=g)
+    target = torch.rand(2, 1, 80, 80, generator=g) * 0.3
+    p = pred.clone().requires_grad_(True)
+    q = torch.sigmoid(p) if sigmoid else p
+    up = F.interpolate(q, size=(80, 80), mode='bilinear', align_corners=False)
+    w = torch.clamp(target * 10, min=0.1, max=1.0) if weighted else 1.0
+    ref = torch.mean(w * torch.abs(up - target))
+    (ref * 3.0).backward()
+    pg = pred.cuda().requires_grad_(True)
+    loss = head.resize_l1_loss(pg, target.cuda(), weighted=weighted, sigmoid=sigmoid)
+    (loss * 3.0).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert (pg.grad.cpu() - p.grad).abs().max().item() < 1e-8 + 1e-5 * p.grad.abs().max().item()
