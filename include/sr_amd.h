@@ -183,8 +183,15 @@ int sr_fdconv_basis(const float* dft_weight, const uint8_t* gmap, float alpha, i
                     void* workspace, size_t workspace_bytes, void* stream);
 /* per-sample weights W_b = sa*ca*fa*hr*sum_g ka_g*basis_g (FDConv.py:644-652,692-697) from the
  * pooled means (B, pooled_ld) -> wdyn [B][9][cout][cin] in dtype. */
-int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, void* wdyn,
-                        void* wdyn_lo, void* stream);
+size_t sr_fdconv_weightgen_workspace_bytes(int B, int cin, int cout);
+int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, int train,
+                        float momentum, void* wdyn, void* wdyn_lo, void* workspace, size_t workspace_bytes, void* stream);
+/* train = 0: KSM_Global's BatchNorm on its running statistics (module.eval()).  train != 0: on the statistics of the batch
+ * of B pooled vectors (nn.BatchNorm2d in train(), FDConv.py:245-258 under model.train() at
+ * train/train_realESRGAN_fdconv_1.py:108); lp->bn_rm / lp->bn_rv are then UPDATED IN PLACE with `momentum` (torch: 0.1;
+ * unbiased variance), B must be 2..512 (torch raises for one value per channel).  The caller bumps num_batches_tracked.
+ * workspace: afterwards holds, per sample, the modulation vectors as floats  ca[cin] | ln[cin] | fa[cout] | sa[9] | ka[4]
+ * (sample stride = (2*cin + cout + 13 + 3) & ~3 floats) -- KSM_Global's four attentions and KSM_Local's LayerNorm output. */
 /* wdyn_lo (may be NULL): the same layout, receives w - wdyn, i.e. the part of each weight that rounding to `dtype` lost.
  * In bf16 the pair (wdyn, wdyn_lo) carries 16 significant bits; sr_conv3x3 multiplies by both when given w_lo_offset.
  * Why: a rounding error in a weight is coherent over every pixel it touches, and through 349 stacked layers with
@@ -216,6 +223,36 @@ int sr_bilinear_resize(const void* src, int src_dtype, void* dst, int dst_dtype,
 size_t sr_resize_l1_workspace_bytes(void);
 int sr_resize_l1_loss(const float* pred, const float* target, long planes, int Hs, int Ws, int Hd, int Wd, int weighted,
                       int pre_sigmoid, float* loss, float* grad_pred, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- training: backward of one conv / FDConv layer ------------------------------------------
+ * The reference obtains these from torch autograd through FDConv.py:640-722 (loss.backward() at
+ * train/train_realESRGAN_fdconv_1.py:117).  Layer forward:  y = bias + conv3x3(a, W_b),  a = FBM(x) (see sr_conv3x3).
+ *
+ * sr_conv_weight_transpose: wt[b][8-t][i][o] = w[b][t][o][i]  ([B][9][cout][cin] -> [B][9][cin][cout], taps mirrored): with
+ *   it  da = sr_conv3x3(dy, wt)  is the gradient wrt the conv operand (adjoint of F.conv2d at FDConv.py:699). */
+int sr_conv_weight_transpose(const void* w, void* wt, int dtype, int B, int cout, int cin, void* stream);
+/* dw[b][t][o][i] = sum_p dy[b,p,o] * a[b, p + off(t), i]  (float32, OVERWRITTEN), a formed from `in` / `gates` exactly as
+ * sr_conv3x3 forms it.  per_sample = 0: one [9][cout][cin] gradient summed over the batch (nn.Conv2d.weight.grad of a plain
+ * layer); != 0: [B][9][cout][cin] (gradient wrt the per-sample dynamic weights, input of the small weight path's backward).
+ * dbias (may be NULL): [cout] = sum over batch and pixels of dy (bias.grad), OVERWRITTEN.  Sums are fp32 atomics: the
+ * order of the partial sums, hence the last bits, vary from run to run. */
+int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, sr_view dy, int cout,
+                     int per_sample, float* dw, float* dbias, void* stream);
+/* backward of the band mix a = g1 x + (g2-g1) L2 + (g3-g2) L4 + (1-g3) L8 (FDConv.py:456-479) given da:
+ *   dx = g1 da, dl2 = (g2-g1) da, dl4 = (g3-g2) da, dl8 = (1-g3) da   (all (B,H,W,C) views in dtype)
+ *   dlogits (B,H,W,4) float = {dz1, dz2, dz3, 0}: gradients wrt the gate-conv outputs z_k (g_k = 2 sigmoid(z_k)),
+ *   dz1 = sum_c da (x - L2) * g1 (1 - g1/2), dz2 with (L2 - L4), dz3 with (L4 - L8). */
+int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_view l2, sr_view l4, sr_view l8, const float* gates, sr_view da,
+                    sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, void* stream);
+/* backward of the three gate convs (FDConv.py:460-461) and assembly of the layer's input gradient:
+ *   dgate_w [3][cin][9], dgate_b [3] (float32, OVERWRITTEN; same atomics remark as sr_conv3x3_wgrad)
+ *   dx_out = dx_direct + a2 + a4 + a8 + conv3x3^T(dlogits; gate_w) + dpooled[b][c] / (H W)
+ * a_k = sr_fbm_lowpass plane k of dl_k (the box low-pass is self-adjoint: a real symmetric mask between a unitary
+ * transform pair); dpooled (B, dpooled_ld) float or NULL: gradient wrt the pooled means (F.adaptive_avg_pool2d at
+ * FDConv.py:643) that the weight path's backward returns.  dx_out may alias dx_direct. */
+int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, const float* dlogits, const sr_layer_params* lp,
+                          sr_view dx_direct, sr_view a2, sr_view a4, sr_view a8, const float* dpooled, int dpooled_ld,
+                          sr_view dx_out, float* dgate_w, float* dgate_b, void* stream);
 
 /* ---- whole network (RRDBNet.forward) ------------------------------------------------------- */
 typedef struct sr_rrdbnet sr_rrdbnet;

@@ -68,7 +68,16 @@ _SIGS = {
     'sr_fdconv_basis_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'sr_fdconv_basis': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
-    'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_fdconv_weightgen_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_int, C.c_float, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_conv_weight_transpose': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_conv3x3_wgrad': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, View, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_fbm_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, View, View, View, C.c_void_p, View, View, View, View,
+                                  View, C.c_void_p, C.c_void_p]),
+    'sr_fbm_gates_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, C.c_void_p, C.POINTER(LayerParams), View, View,
+                                        View, View, C.c_void_p, C.c_int, View, C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_conv3x3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, C.c_void_p, C.c_long, C.c_long,
                              C.c_int, C.POINTER(Epilogue), View, C.c_void_p]),
     'sr_pixel_shuffle_add': (C.c_int, [View, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -198,7 +198,10 @@ struct GateConsList {
 };
 
 int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, hipStream_t st);  // bf16; SR_NOT_ELIGIBLE
-int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,
-                     void* wdyn_lo, hipStream_t st);
+// mods: weightgen_ws_bytes(B, cin, cout) of scratch (the modulation vectors ca | ln | fa | sa | ka per sample stay there);
+// train: BatchNorm on batch statistics, lp.bn_rm / lp.bn_rv updated in place with `momentum`
+size_t weightgen_ws_bytes(int B, int cin, int cout);
+int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, int train, float momentum,
+                     void* wdyn, void* wdyn_lo, float* mods, hipStream_t st);
 
 }  // namespace sr

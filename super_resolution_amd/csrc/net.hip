@@ -60,7 +60,7 @@ int g_split_weights = 1;  // bf16: dynamic weights as hi + lo pairs (test hook s
 enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4, G_HEAD = 5, G_LOWPASS_HR = 6, G_NGROUPS = 8 };
 
 struct Layout {
-    size_t in0, f0, trunk[3], xg[4], band64, bandg[4], gates, logit[5], pooled, wdyn, fft, u1, band_u1, u2, u3, band_hr, outp;
+    size_t in0, f0, trunk[3], xg[4], band64, bandg[4], gates, logit[5], pooled, mods, wdyn, fft, u1, band_u1, u2, u3, band_hr, outp;
     size_t total;
 };
 
@@ -100,9 +100,12 @@ Layout make_layout(const sr_rrdbnet* net, int dtype, int B, int H, int W) {
         for (int i = 0; i < 5; ++i) L.logit[i] = carve(n1 * 3 * sizeof(float));  // dense-block gate accumulators
         const int cmax = net->nf + 4 * net->gc;
         L.pooled = carve((size_t)B * cmax * sizeof(float));
-        size_t wmax = 0;  // largest cout * cin over the layers (conv4 beats conv5 when num_grow_ch > num_feat)
-        for (const sr_layer_params& lp : net->layers)
+        size_t wmax = 0, mmax = 0;  // largest cout * cin over the layers (conv4 beats conv5 when num_grow_ch > num_feat)
+        for (const sr_layer_params& lp : net->layers) {
             if ((size_t)lp.cout * lp.cin > wmax) wmax = (size_t)lp.cout * lp.cin;
+            if (lp.active && weightgen_ws_bytes(B, lp.cin, lp.cout) > mmax) mmax = weightgen_ws_bytes(B, lp.cin, lp.cout);
+        }
+        L.mods = carve(mmax);
         L.wdyn = carve(2 * (size_t)B * 9 * wmax * es);  // high and low parts (bf16: w = hi + lo)
         L.fft = carve(fft_ws_need(net, B, H, W));
     }
@@ -209,8 +212,8 @@ struct Run {
             if (fork && (hipEventRecord(net->ev_fork, st) != hipSuccess || hipStreamWaitEvent(net->side, net->ev_fork, 0) != hipSuccess)) { rc = SR_ERR_HIP; return; }
             prof_begin(G_WGEN, wgs);
             const long wlo = dtype == SR_BF16 && g_split_weights ? (long)B * 9 * lp.cout * lp.cin : 0;  // elements from hi to lo
-            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, ws + L.wdyn,
-                                  wlo ? ws + L.wdyn + (size_t)wlo * es : nullptr, wgs);
+            rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, 0, 0.f, ws + L.wdyn,
+                                  wlo ? ws + L.wdyn + (size_t)wlo * es : nullptr, (float*)(ws + L.mods), wgs);
             prof_end(wgs);
             if (rc != SR_OK) return;
             if (fork && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }

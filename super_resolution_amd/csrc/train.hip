@@ -1,0 +1,379 @@
+// Backward kernels of the FDConv / conv layers (training step of train/train_realESRGAN_fdconv_1.py:113-118: the reference
+// gets these from torch autograd through FDConv.py:640-722).  Every tensor is NHWC in `dtype`; sums run in float32.
+//
+//   y[b,p,o] = bias[o] + sum_{t,i} W_b[t][o][i] * a[b, p + off(t), i],   a = FBM(x) = g1 x + (g2-g1) L2 + (g3-g2) L4 + (1-g3) L8
+//
+//   sr_conv_weight_transpose : W^T with mirrored taps, the operand with which sr_conv3x3 computes da = conv(dy, W^T)
+//   sr_conv3x3_wgrad         : dW_b[t][o][i] = sum_p dy[b,p,o] a[b,p+off(t),i]  (a formed on the fly, as the forward loader
+//                              does), dbias[o] = sum dy
+//   sr_fbm_backward          : da -> the four linear branches (dx, dL2, dL4, dL8) and the gate-logit gradients
+//   sr_fbm_gates_backward    : gate-conv weight / bias gradients and the assembly of the layer's input gradient
+//                              (direct branch + the three low-passed band branches + transposed gate conv + pooled mean)
+// The box low-pass is self-adjoint (a real symmetric mask between a unitary transform pair), so the band branches go
+// back through sr_fbm_lowpass itself.
+#include "common.h"
+
+namespace sr {
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void weight_transpose_kernel(const T* __restrict__ w, T* __restrict__ wt, int B, int cout, int cin) {
+    const long n = (long)B * 9 * cout * cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // destination index: [b][t'][i][o]
+        const int o = (int)(i % cout);
+        long r = i / cout;
+        const int ci = (int)(r % cin);
+        r /= cin;
+        const int tp = (int)(r % 9);
+        const long b = r / 9;
+        wt[i] = w[((b * 9 + (8 - tp)) * cout + o) * cin + ci];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient.  Workgroup: a 32 x 32 (o, i) block of all 9 taps for a run of 4-row x 32-column pixel strips of one
+// sample; thread (to, ti) keeps a 2 x 2 (o, i) patch x 9 taps in registers.  The dy strip and the haloed operand strip
+// are staged in LDS (reads are broadcasts: 16 lanes share a dy address, 4 share an operand address).
+constexpr int WG_RS = 4, WG_WC = 32;
+
+template <typename T>
+__device__ __forceinline__ float operand_at(const Concat& in, const float* __restrict__ gates, int b, int H, int W, int h, int w,
+                                            int ci) {
+    if (h < 0 || h >= H || w < 0 || w >= W || ci >= in.ctot) return 0.f;
+    int s = 0;
+    while (s + 1 < in.nseg && ci >= in.cstart[s + 1]) ++s;
+    const int c = ci - in.cstart[s];
+    const int Ws = W >> in.ups;
+    float v = Elem<T>::ld((const T*)in.x[s].p + voff(in.x[s], b, (long)(h >> in.ups) * Ws + (w >> in.ups), c));
+    if (in.bands) {
+        const long p = (long)h * W + w;
+        const float4 g = ((const float4*)gates)[(long)b * H * W + p];
+        const float v2 = Elem<T>::ld((const T*)in.l2[s].p + voff(in.l2[s], b, p, c));
+        const float v4 = Elem<T>::ld((const T*)in.l4[s].p + voff(in.l4[s], b, p, c));
+        const float v8 = Elem<T>::ld((const T*)in.l8[s].p + voff(in.l8[s], b, p, c));
+        v = g.x * v + (g.y - g.x) * v2 + (g.z - g.y) * v4 + (1.0f - g.z) * v8;
+    }
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(Concat in, int H, int W, const float* __restrict__ gates, View dy, int cout,
+                                                    float* __restrict__ dw, long dw_bstride, int strips_per_block) {
+    __shared__ __attribute__((aligned(16))) float a_sh[WG_RS + 2][WG_WC + 2][32];
+    __shared__ __attribute__((aligned(16))) float d_sh[WG_RS][WG_WC][32];
+    const int cin = in.ctot;
+    const int itiles = (cin + 31) / 32;
+    const int i0 = (blockIdx.x % itiles) * 32, o0 = (blockIdx.x / itiles) * 32;
+    const int b = blockIdx.z;
+    const int sx = (W + WG_WC - 1) / WG_WC, nstrips = sx * ((H + WG_RS - 1) / WG_RS);
+    const int tid = threadIdx.x, to = tid >> 4, ti = tid & 15;
+    float acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0.f;
+    const int s_begin = blockIdx.y * strips_per_block;
+    const int s_end = min(nstrips, s_begin + strips_per_block);
+    for (int st = s_begin; st < s_end; ++st) {
+        const int h0 = (st / sx) * WG_RS, w0 = (st % sx) * WG_WC;
+        __syncthreads();
+        for (int it = tid; it < (WG_RS + 2) * (WG_WC + 2) * 32; it += 256) {
+            const int c = it & 31, pi = it >> 5;
+            const int py = pi / (WG_WC + 2), px = pi - py * (WG_WC + 2);
+            a_sh[py][px][c] = operand_at<T>(in, gates, b, H, W, h0 + py - 1, w0 + px - 1, i0 + c);
+        }
+        for (int it = tid; it < WG_RS * WG_WC * 32; it += 256) {
+            const int c = it & 31, pi = it >> 5;
+            const int py = pi / WG_WC, px = pi - py * WG_WC;
+            const int h = h0 + py, w = w0 + px;
+            float v = 0.f;
+            if (h < H && w < W && o0 + c < cout) v = Elem<T>::ld((const T*)dy.p + voff(dy, b, (long)h * W + w, o0 + c));
+            d_sh[py][px][c] = v;
+        }
+        __syncthreads();
+        for (int py = 0; py < WG_RS; ++py)
+            for (int px = 0; px < WG_WC; ++px) {
+                const float2 d = *(const float2*)&d_sh[py][px][2 * to];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float2 a = *(const float2*)&a_sh[py + t / 3][px + t % 3][2 * ti];
+                    acc[t][0][0] += d.x * a.x;
+                    acc[t][0][1] += d.x * a.y;
+                    acc[t][1][0] += d.y * a.x;
+                    acc[t][1][1] += d.y * a.y;
+                }
+            }
+    }
+    float* out = dw + (long)b * dw_bstride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int o = o0 + 2 * to + oo, ci = i0 + 2 * ti + ii;
+                if (o < cout && ci < cin) atomicAdd(out + ((long)t * cout + o) * cin + ci, acc[t][oo][ii]);
+            }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(View dy, long npix, long total_pix, int cout, float* __restrict__ dbias,
+                                                        int pix_per_block) {
+    __shared__ float sh[256];
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = min(total_pix, p0 + pix_per_block);
+    for (int ob = 0; ob < cout; ob += 256) {
+        const int nc = min(256, cout - ob);
+        const int sub = threadIdx.x / nc, nsub = 256 / nc, c = threadIdx.x - sub * nc;
+        float s = 0.f;
+        if (sub < nsub)
+            for (long p = p0 + sub; p < p1; p += nsub) s += Elem<T>::ld((const T*)dy.p + voff(dy, (int)(p / npix), p % npix, ob + c));
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < nc) {
+            float tot = 0.f;
+            for (int k = 0; k < nsub; ++k) tot += sh[k * nc + threadIdx.x];
+            atomicAdd(dbias + ob + threadIdx.x, tot);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FBM backward: one wavefront per pixel, lanes over channels
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fbm_backward_kernel(long total_pix, long npix, int C, View x, View l2, View l4, View l8,
+                                                           const float* __restrict__ gates, View da, View dx, View dl2, View dl4,
+                                                           View dl8, float* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long pg = wave0; pg < total_pix; pg += nwaves) {
+        const int b = (int)(pg / npix);
+        const long p = pg - (long)b * npix;
+        const float4 g = ((const float4*)gates)[pg];
+        const float c1 = g.y - g.x, c2 = g.z - g.y, c3 = 1.0f - g.z;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = Elem<T>::ld((const T*)da.p + voff(da, b, p, c));
+            const float xv = Elem<T>::ld((const T*)x.p + voff(x, b, p, c));
+            const float v2 = Elem<T>::ld((const T*)l2.p + voff(l2, b, p, c));
+            const float v4 = Elem<T>::ld((const T*)l4.p + voff(l4, b, p, c));
+            const float v8 = Elem<T>::ld((const T*)l8.p + voff(l8, b, p, c));
+            s1 += d * (xv - v2);
+            s2 += d * (v2 - v4);
+            s3 += d * (v4 - v8);
+            Elem<T>::st((T*)dx.p + voff(dx, b, p, c), g.x * d);
+            Elem<T>::st((T*)dl2.p + voff(dl2, b, p, c), c1 * d);
+            Elem<T>::st((T*)dl4.p + voff(dl4, b, p, c), c2 * d);
+            Elem<T>::st((T*)dl8.p + voff(dl8, b, p, c), c3 * d);
+        }
+        s1 = wsum(s1);
+        s2 = wsum(s2);
+        s3 = wsum(s3);
+        // g = 2 sigmoid(z)  ->  dg/dz = g (1 - g/2)
+        if (lane == 0)
+            ((float4*)dlogits)[pg] = make_float4(s1 * g.x * (1.0f - 0.5f * g.x), s2 * g.y * (1.0f - 0.5f * g.y),
+                                                 s3 * g.z * (1.0f - 0.5f * g.z), 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// input-gradient assembly: dx = dx_direct + a2 + a4 + a8 + sum_{k,t} gw[k][c][t] dz_k[p - off(t)] + dpooled[b][c] / (H W)
+template <typename T>
+__global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, int C, const float* __restrict__ dz, sr_layer_params lp,
+                                                         View dxd, View a2, View a4, View a8, const float* __restrict__ dpooled,
+                                                         int dpooled_ld, View out) {
+    const long npix = (long)H * W, total = (long)B * npix * C;
+    const float inv = 1.0f / (float)npix;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pg = i / C;
+        const int b = (int)(pg / npix);
+        const long p = pg - (long)b * npix;
+        const int h = (int)(p / W), w = (int)(p - (long)h * W);
+        float v = Elem<T>::ld((const T*)dxd.p + voff(dxd, b, p, c)) + Elem<T>::ld((const T*)a2.p + voff(a2, b, p, c)) +
+                  Elem<T>::ld((const T*)a4.p + voff(a4, b, p, c)) + Elem<T>::ld((const T*)a8.p + voff(a8, b, p, c));
+        if (dpooled) v += dpooled[(long)b * dpooled_ld + c] * inv;
+        float gsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            const float4 d = ((const float4*)dz)[(long)b * npix + (long)hh * W + ww];
+            gsum += lp.gate_w[0][c * 9 + t] * d.x + lp.gate_w[1][c * 9 + t] * d.y + lp.gate_w[2][c * 9 + t] * d.z;
+        }
+        Elem<T>::st((T*)out.p + voff(out, b, p, c), v + gsum);
+    }
+}
+
+// gate-conv weight / bias gradients: workgroup = 64 channels x a run of pixels; lane <-> channel, the 4 waves take
+// interleaved pixels; dgw[k][c][t] += x[q][c] * dz_k[q - off(t)]
+template <typename T>
+__global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, int C, View x, const float* __restrict__ dz,
+                                                         float* __restrict__ dgw, float* __restrict__ dgb, int pix_per_block) {
+    __shared__ float red[4][27][64];
+    const long npix = (long)H * W, total = (long)B * npix;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const long q0 = (long)blockIdx.x * pix_per_block, q1 = min(total, q0 + pix_per_block);
+    float acc[3][9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[k][t] = 0.f;
+    float bsum[3] = {0.f, 0.f, 0.f};
+    for (long qg = q0 + wave; qg < q1; qg += 4) {
+        const int b = (int)(qg / npix);
+        const long q = qg - (long)b * npix;
+        const int h = (int)(q / W), w = (int)(q - (long)h * W);
+        const float xv = c < C ? Elem<T>::ld((const T*)x.p + voff(x, b, q, c)) : 0.f;
+        if (blockIdx.y == 0 && lane == 0) {
+            const float4 d = ((const float4*)dz)[qg];
+            bsum[0] += d.x;
+            bsum[1] += d.y;
+            bsum[2] += d.z;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            const float4 d = ((const float4*)dz)[(long)b * npix + (long)hh * W + ww];
+            acc[0][t] += xv * d.x;
+            acc[1][t] += xv * d.y;
+            acc[2][t] += xv * d.z;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[wave][k * 9 + t][lane] = acc[k][t];
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int j = k * 9 + t;
+                atomicAdd(dgw + ((long)k * C + c) * 9 + t, red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane]);
+            }
+    }
+    if (blockIdx.y == 0 && lane == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(dgb + k, bsum[k]);
+}
+
+static bool plain_view_ok(const sr_view& v, int C) {
+    return v.p && v.C == C && v.c0 >= 0 && v.ld >= 1 && (v.cbs || v.c0 + v.C <= v.ld) && view_block_ok(v);
+}
+
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" int sr_conv_weight_transpose(const void* w, void* wt, int dtype, int B, int cout, int cin, void* stream) {
+    SR_REQUIRE(w && wt && w != wt && dtype_ok(dtype) && B > 0 && cout > 0 && cin > 0);
+    const long n = (long)B * 9 * cout * cin;
+    const int grid = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SR_F32)
+        weight_transpose_kernel<float><<<grid, 256, 0, st>>>((const float*)w, (float*)wt, B, cout, cin);
+    else
+        weight_transpose_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)w, (bf16_t*)wt, B, cout, cin);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, sr_view dy, int cout,
+                                int per_sample, float* dw, float* dbias, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && B <= 65535 && H > 0 && W > 0 && in && cout > 0 && dw && plain_view_ok(dy, cout));
+    SR_REQUIRE(!in->ups || (H % 2 == 0 && W % 2 == 0));
+    const long npix = (long)H * W;
+    Concat c;
+    int rc = to_concat(in, in->ups ? npix / 4 : npix, npix, &c);
+    if (rc != SR_OK) return rc;
+    SR_REQUIRE(!c.bands || gates);
+    hipStream_t st = (hipStream_t)stream;
+    const int cin = c.ctot;
+    const long wn = 9L * cout * cin;
+    SR_HIP(hipMemsetAsync(dw, 0, (size_t)(per_sample ? B : 1) * wn * sizeof(float), st));
+    const int tiles = cdiv(cin, 32) * cdiv(cout, 32);
+    const int nstrips = cdiv(W, WG_WC) * cdiv(H, WG_RS);
+    // enough workgroups to fill the chip, but as few atomic rounds as that allows
+    int spb = (int)(((long)nstrips * tiles * B + 2047) / 2048);
+    if (spb < 1) spb = 1;
+    dim3 grid(tiles, cdiv(nstrips, spb), B);
+    const View dyv = to_view(dy, npix);
+    if (dtype == SR_F32)
+        wgrad_kernel<float><<<grid, 256, 0, st>>>(c, H, W, gates, dyv, cout, dw, per_sample ? wn : 0, spb);
+    else
+        wgrad_kernel<bf16_t><<<grid, 256, 0, st>>>(c, H, W, gates, dyv, cout, dw, per_sample ? wn : 0, spb);
+    SR_LAUNCH_CHECK();
+    if (dbias) {
+        SR_HIP(hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), st));
+        const long total = (long)B * npix;
+        const int ppb = 2048;
+        if (dtype == SR_F32)
+            bias_grad_kernel<float><<<cdiv(total, ppb), 256, 0, st>>>(dyv, npix, total, cout, dbias, ppb);
+        else
+            bias_grad_kernel<bf16_t><<<cdiv(total, ppb), 256, 0, st>>>(dyv, npix, total, cout, dbias, ppb);
+        SR_LAUNCH_CHECK();
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_view l2, sr_view l4, sr_view l8, const float* gates,
+                               sr_view da, sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && gates && dlogits && x.C > 0);
+    const int C = x.C;
+    const sr_view* vs[9] = {&x, &l2, &l4, &l8, &da, &dx, &dl2, &dl4, &dl8};
+    for (const sr_view* v : vs) SR_REQUIRE(plain_view_ok(*v, C));
+    const long npix = (long)H * W, total = (long)B * npix;
+    const int grid = (int)((total + 3) / 4 < 16384 ? (total + 3) / 4 : 16384);
+    hipStream_t st = (hipStream_t)stream;
+#define SR_FB(T)                                                                                                                 \
+    fbm_backward_kernel<T><<<grid, 256, 0, st>>>(total, npix, C, to_view(x, npix), to_view(l2, npix), to_view(l4, npix),      \
+                                                 to_view(l8, npix), gates, to_view(da, npix), to_view(dx, npix),                \
+                                                 to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits)
+    if (dtype == SR_F32) SR_FB(float);
+    else SR_FB(bf16_t);
+#undef SR_FB
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, const float* dlogits, const sr_layer_params* lp,
+                                     sr_view dx_direct, sr_view a2, sr_view a4, sr_view a8, const float* dpooled, int dpooled_ld,
+                                     sr_view dx_out, float* dgate_w, float* dgate_b, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && dlogits && lp && dgate_w && dgate_b && x.C > 0 && x.C == lp->cin);
+    SR_REQUIRE(lp->gate_w[0] && lp->gate_w[1] && lp->gate_w[2]);
+    SR_REQUIRE(!dpooled || dpooled_ld >= x.C);
+    const int C = x.C;
+    const sr_view* vs[6] = {&x, &dx_direct, &a2, &a4, &a8, &dx_out};
+    for (const sr_view* v : vs) SR_REQUIRE(plain_view_ok(*v, C));
+    const long npix = (long)H * W, total = (long)B * npix;
+    hipStream_t st = (hipStream_t)stream;
+    SR_HIP(hipMemsetAsync(dgate_w, 0, (size_t)27 * C * sizeof(float), st));
+    SR_HIP(hipMemsetAsync(dgate_b, 0, 3 * sizeof(float), st));
+    const long n = total * C;
+    const int g1 = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+    const int ppb = 1024;
+    dim3 g2(cdiv(total, ppb), cdiv(C, 64));
+#define SR_GB(T)                                                                                                                 \
+    do {                                                                                                                         \
+        input_grad_kernel<T><<<g1, 256, 0, st>>>(B, H, W, C, dlogits, *lp, to_view(dx_direct, npix), to_view(a2, npix),         \
+                                                 to_view(a4, npix), to_view(a8, npix), dpooled, dpooled_ld, to_view(dx_out, npix)); \
+        SR_LAUNCH_CHECK();                                                                                                       \
+        gate_wgrad_kernel<T><<<g2, 256, 0, st>>>(B, H, W, C, to_view(x, npix), dlogits, dgate_w, dgate_b, ppb);                  \
+        SR_LAUNCH_CHECK();                                                                                                       \
+    } while (0)
+    if (dtype == SR_F32) SR_GB(float);
+    else SR_GB(bf16_t);
+#undef SR_GB
+    return SR_OK;
+}

@@ -2,7 +2,7 @@
 //   sr_fdconv_basis     : Basis_g = irfft2(alpha * dft_weight * [group == g])  (FDConv.py:661-684)
 //                         run once per weight update; exact two-stage inverse real DFT in fp64.
 //   sr_fdconv_weightgen : per-sample dynamic weights from the pooled means (FDConv.py:643-652, 690-697)
-//                         KSM_Global (fc -> BN(eval) -> StarReLU -> 4 sigmoid heads), KSM_Local
+//                         KSM_Global (fc -> BN (running or batch statistics) -> StarReLU -> 4 sigmoid heads), KSM_Local
 //                         (LayerNorm + k-tap conv along the channel axis), and
 //                         W_b = sa * ca * fa * hr * sum_g ka_g * Basis_g, written in the conv kernels'
 //                         [tap][cout][cin] operand layout.
@@ -63,104 +63,172 @@ __global__ void basis_stage_b(const double2* __restrict__ Z, float alpha, int co
 }
 
 // ---- per-sample weights -------------------------------------------------------------------
+// Two launches per layer:
+//   ksm_kernel       one workgroup of 16 waves for the whole batch: KSM_Global (fc -> BatchNorm -> StarReLU -> four
+//                    sigmoid heads) and KSM_Local's LayerNorm.  Every dot product over the input channels is a
+//                    wavefront reduction (lanes over cin, DPP/permute butterfly); BatchNorm sees the whole batch, so
+//                    train mode (statistics over the batch of pooled vectors, FDConv.py:245-258 with nn.BatchNorm2d in
+//                    train()) is the same kernel.  Result: the modulation vectors `mods` [B][ms] in global memory:
+//                      ca[cin] | ln[cin] | fa[cout] | sa[9] | ka[4]      (ms = mods_stride(cin, cout))
+//   aggregate_kernel one work item per (sample, o, ci): the 9 taps of W_b = sa*ca*fa*hr*sum_g ka_g*Basis_g, KSM_Local's
+//                    k-tap conv along the channel axis formed on the way; cout*cin/256 x B workgroups.
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void weightgen_kernel(const float* __restrict__ pooled, int pooled_ld,
-                                                        sr_layer_params lp, T* __restrict__ wdyn, T* __restrict__ wdyn_lo,
-                                                        int o_per_block) {
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__host__ __device__ inline int mods_stride(int cin, int cout) { return (2 * cin + cout + 9 + KN + 3) & ~3; }
+
+template <bool TRAIN>
+__global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp, int B,
+                                                   float momentum, float* __restrict__ mods) {
     extern __shared__ float sh[];
-    const int cin = lp.cin, cout = lp.cout, taps = lp.loc_taps;
-    float* g = sh;              // [cin] pooled means
-    float* ln = g + cin;        // [cin] LayerNorm(g)
-    float* ca = ln + cin;       // [cin]
-    float* fa = ca + cin;       // [cout]
-    float* a = fa + cout;       // [ATT]
-    float* sa = a + ATT;        // [9]
-    float* ka = sa + 9;         // [KN]
-    float* red = ka + KN;       // [2]
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < cin; i += blockDim.x) g[i] = pooled[(long)b * pooled_ld + i];
+    const int cin = lp.cin, cout = lp.cout;
+    const int ms = mods_stride(cin, cout);
+    float* z = sh;                 // [B][ATT] fc outputs, then StarReLU activations
+    float* mean = z + B * ATT;     // [ATT]
+    float* var = mean + ATT;       // [ATT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    // fc (no bias): one wavefront reduction per (sample, attention channel)
+    for (int pair = wave; pair < B * ATT; pair += nw) {
+        const int b = pair / ATT, k = pair - b * ATT;
+        const float* g = pooled + (long)b * pooled_ld;
+        const float* w = lp.fc_w + (long)k * cin;
+        float s = 0.f;
+        for (int i = lane; i < cin; i += 64) s += w[i] * g[i];
+        s = wave_sum(s);
+        if (lane == 0) z[pair] = s;
+    }
     __syncthreads();
-    // KSM_Global: fc (no bias) -> BatchNorm (running stats) -> StarReLU
+    // BatchNorm statistics: running (eval) or over the batch (train; biased variance normalises, the unbiased one goes
+    // into the running estimate, as nn.BatchNorm2d does)
     if (tid < ATT) {
-        float z = 0.f;
-        for (int i = 0; i < cin; ++i) z += lp.fc_w[tid * cin + i] * g[i];
-        z = (z - lp.bn_rm[tid]) / sqrtf(lp.bn_rv[tid] + 1e-5f) * lp.bn_w[tid] + lp.bn_b[tid];
-        const float r = fmaxf(z, 0.f);
-        a[tid] = lp.relu_s[0] * r * r + lp.relu_b[0];
-    }
-    // KSM_Local: LayerNorm statistics over the channel axis (biased variance, eps 1e-5)
-    if (tid == 64) {
-        float m = 0.f;
-        for (int i = 0; i < cin; ++i) m += g[i];
-        m /= cin;
-        float v = 0.f;
-        for (int i = 0; i < cin; ++i) v += (g[i] - m) * (g[i] - m);
-        v /= cin;
-        red[0] = m;
-        red[1] = 1.0f / sqrtf(v + 1e-5f);
-    }
-    __syncthreads();
-    for (int i = tid; i < cin; i += blockDim.x) {
-        ln[i] = (g[i] - red[0]) * red[1] * lp.ln_w[i] + lp.ln_b[i];
-        float z = lp.ch_b[i];
-        for (int k = 0; k < ATT; ++k) z += lp.ch_w[i * ATT + k] * a[k];
-        ca[i] = 2.0f * sigmoidf(z);
-    }
-    for (int i = tid; i < cout; i += blockDim.x) {
-        float z = lp.fl_b[i];
-        for (int k = 0; k < ATT; ++k) z += lp.fl_w[i * ATT + k] * a[k];
-        fa[i] = 2.0f * sigmoidf(z);
-    }
-    if (tid < 9) {
-        float z = lp.sp_b[tid];
-        for (int k = 0; k < ATT; ++k) z += lp.sp_w[tid * ATT + k] * a[k];
-        sa[tid] = 2.0f * sigmoidf(z);
-    }
-    if (tid >= 32 && tid < 32 + KN) {
-        const int q = tid - 32;
-        float z = lp.kn_b[q];
-        for (int k = 0; k < ATT; ++k) z += lp.kn_w[q * ATT + k] * a[k];
-        ka[q] = sigmoidf(z) * 2.0f / KN;
+        if (TRAIN) {
+            float m = 0.f;
+            for (int b = 0; b < B; ++b) m += z[b * ATT + tid];
+            m /= B;
+            float v = 0.f;
+            for (int b = 0; b < B; ++b) v += (z[b * ATT + tid] - m) * (z[b * ATT + tid] - m);
+            mean[tid] = m;
+            var[tid] = v / B;
+            float* rm = const_cast<float*>(lp.bn_rm);
+            float* rv = const_cast<float*>(lp.bn_rv);
+            rm[tid] = (1.0f - momentum) * rm[tid] + momentum * m;
+            rv[tid] = (1.0f - momentum) * rv[tid] + momentum * (v / (B - 1));
+        } else {
+            mean[tid] = lp.bn_rm[tid];
+            var[tid] = lp.bn_rv[tid];
+        }
     }
     __syncthreads();
-    // aggregate: one item per (o, tap, ci); ci innermost so stores are contiguous
-    const int o0 = blockIdx.y * o_per_block;
-    const int o1 = min(cout, o0 + o_per_block);
-    const int pad = (taps - 1) / 2;
+    for (int i = tid; i < B * ATT; i += blockDim.x) {
+        const int k = i % ATT;
+        const float zn = (z[i] - mean[k]) / sqrtf(var[k] + 1e-5f) * lp.bn_w[k] + lp.bn_b[k];
+        const float r = fmaxf(zn, 0.f);
+        z[i] = lp.relu_s[0] * r * r + lp.relu_b[0];
+    }
+    __syncthreads();
+    // heads: one work item per (sample, output); rows of 16 weights
+    const int per = cin + cout + 9 + KN;
+    for (int it = tid; it < B * per; it += blockDim.x) {
+        const int b = it / per, j = it - b * per;
+        const float *w, *bias;
+        int row, at;
+        float scale = 2.0f;
+        if (j < cin) { row = j; w = lp.ch_w; bias = lp.ch_b; at = j; }
+        else if (j < cin + cout) { row = j - cin; w = lp.fl_w; bias = lp.fl_b; at = 2 * cin + row; }
+        else if (j < cin + cout + 9) { row = j - cin - cout; w = lp.sp_w; bias = lp.sp_b; at = 2 * cin + cout + row; }
+        else { row = j - cin - cout - 9; w = lp.kn_w; bias = lp.kn_b; at = 2 * cin + cout + 9 + row; scale = 2.0f / KN; }
+        float s = bias[row];
+#pragma unroll
+        for (int k = 0; k < ATT; ++k) s += w[row * ATT + k] * z[b * ATT + k];
+        mods[(long)b * ms + at] = scale * sigmoidf(s);
+    }
+    // KSM_Local: LayerNorm over the channel axis (biased variance, eps 1e-5), one wavefront per sample
+    for (int b = wave; b < B; b += nw) {
+        const float* g = pooled + (long)b * pooled_ld;
+        float s = 0.f;
+        for (int i = lane; i < cin; i += 64) s += g[i];
+        const float m = wave_sum(s) / cin;
+        float q = 0.f;
+        for (int i = lane; i < cin; i += 64) q += (g[i] - m) * (g[i] - m);
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / cin + 1e-5f);
+        for (int i = lane; i < cin; i += 64) mods[(long)b * ms + cin + i] = (g[i] - m) * rstd * lp.ln_w[i] + lp.ln_b[i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ mods, sr_layer_params lp, T* __restrict__ wdyn,
+                                                        T* __restrict__ wdyn_lo) {
+    const int cin = lp.cin, cout = lp.cout, taps = lp.loc_taps, pad = (taps - 1) / 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cout * cin) return;
+    const int b = blockIdx.y;
+    const int o = idx / cin, ci = idx - o * cin;
+    const float* md = mods + (long)b * mods_stride(cin, cout);
+    const float* ln = md + cin;
+    const float* sa = md + 2 * cin + cout;
+    const float* ka = sa + 9;
+    const float cf = md[ci] * md[2 * cin + o];  // ca * fa
+    float lnw[15];
+#pragma unroll
+    for (int t = 0; t < 15; ++t) {
+        const int j = ci + t - pad;
+        lnw[t] = (t < taps && j >= 0 && j < cin) ? ln[j] : 0.f;
+    }
+    float ad[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) ad[tap] = 0.f;
+#pragma unroll
+    for (int q = 0; q < KN; ++q) {
+        const float* bs = lp.basis + (((long)q * cout + o) * cin + ci) * 9;
+        const float k = ka[q];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) ad[tap] += k * bs[tap];
+    }
     const long bstride = 9L * cout * cin;
-    for (int it = tid; it < (o1 - o0) * 9 * cin; it += blockDim.x) {
-        const int ci = it % cin;
-        const int tap = (it / cin) % 9;
-        const int o = o0 + it / (9 * cin);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
         const float* lw = lp.loc_w + (long)(o * 9 + tap) * taps;
         float logit = 0.f;
-        for (int t = 0; t < taps; ++t) {
-            const int j = ci + t - pad;
-            if (j >= 0 && j < cin) logit += lw[t] * ln[j];
-        }
-        const float hr = 2.0f * sigmoidf(logit);
-        float ad = 0.f;
 #pragma unroll
-        for (int q = 0; q < KN; ++q) ad += ka[q] * lp.basis[(((long)q * cout + o) * cin + ci) * 9 + tap];
-        const float w = sa[tap] * ca[ci] * fa[o] * ad * hr;
+        for (int t = 0; t < 15; ++t)
+            if (t < taps) logit += lw[t] * lnw[t];
+        const float hr = 2.0f * sigmoidf(logit);
+        const float w = sa[tap] * cf * ad[tap] * hr;
         const long at = b * bstride + ((long)tap * cout + o) * cin + ci;
         Elem<T>::st(wdyn + at, w);
         if (wdyn_lo) Elem<T>::st(wdyn_lo + at, w - Elem<T>::ld(wdyn + at));  // w = hi + lo, both in T (bf16: 16 significant bits)
     }
 }
 
-int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, void* wdyn,
-                     void* wdyn_lo, hipStream_t st) {
-    const int opb = 8;
-    dim3 grid(B, cdiv(lp.cout, opb));
-    const size_t sh = (3 * lp.cin + lp.cout + ATT + 9 + KN + 2) * sizeof(float);
+constexpr int KSM_MAX_B = 512;  // batch rows one ksm_kernel launch keeps in LDS (32 KiB of fc outputs)
+
+size_t weightgen_ws_bytes(int B, int cin, int cout) { return align_up((size_t)B * mods_stride(cin, cout) * sizeof(float), 256); }
+
+int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, int train, float momentum,
+                     void* wdyn, void* wdyn_lo, float* mods, hipStream_t st) {
+    if (lp.loc_taps > 15) return SR_ERR_ARG;
+    if (train && (B < 2 || B > KSM_MAX_B)) return SR_ERR_ARG;  // BatchNorm needs more than one value per channel
+    const int ms = mods_stride(lp.cin, lp.cout);
+    for (int b0 = 0; b0 < B; b0 += KSM_MAX_B) {
+        const int nb = B - b0 < KSM_MAX_B ? B - b0 : KSM_MAX_B;
+        const size_t sh = ((size_t)nb * ATT + 2 * ATT) * sizeof(float);
+        const int threads = nb >= 4 ? 1024 : 256;
+        if (train)
+            ksm_kernel<true><<<1, threads, sh, st>>>(pooled + (long)b0 * pooled_ld, pooled_ld, lp, nb, momentum, mods + (long)b0 * ms);
+        else
+            ksm_kernel<false><<<1, threads, sh, st>>>(pooled + (long)b0 * pooled_ld, pooled_ld, lp, nb, momentum, mods + (long)b0 * ms);
+        SR_LAUNCH_CHECK();
+    }
+    dim3 grid(cdiv((long)lp.cout * lp.cin, 256), B);
     if (dtype == SR_F32)
-        weightgen_kernel<float><<<grid, 256, sh, st>>>(pooled, pooled_ld, lp, (float*)wdyn, (float*)wdyn_lo, opb);
+        aggregate_kernel<float><<<grid, 256, 0, st>>>(mods, lp, (float*)wdyn, (float*)wdyn_lo);
     else
-        weightgen_kernel<bf16_t><<<grid, 256, sh, st>>>(pooled, pooled_ld, lp, (bf16_t*)wdyn, (bf16_t*)wdyn_lo, opb);
+        aggregate_kernel<bf16_t><<<grid, 256, 0, st>>>(mods, lp, (bf16_t*)wdyn, (bf16_t*)wdyn_lo);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -195,8 +263,16 @@ extern "C" int sr_fdconv_basis(const float* dft_weight, const uint8_t* gmap, flo
     return SR_OK;
 }
 
-extern "C" int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp,
-                                   void* wdyn, void* wdyn_lo, void* stream) {
-    SR_REQUIRE(dtype_ok(dtype) && B > 0 && pooled && wdyn && layer_ok_active(lp) && pooled_ld >= lp->cin);
-    return weightgen_launch(dtype, B, pooled, pooled_ld, *lp, wdyn, wdyn_lo, (hipStream_t)stream);
+extern "C" size_t sr_fdconv_weightgen_workspace_bytes(int B, int cin, int cout) {
+    if (B < 1 || cin < 1 || cout < 1) return 0;
+    return weightgen_ws_bytes(B, cin, cout);
+}
+
+extern "C" int sr_fdconv_weightgen(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, int train,
+                                   float momentum, void* wdyn, void* wdyn_lo, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && B <= 65535 && pooled && wdyn && workspace && layer_ok_active(lp) && pooled_ld >= lp->cin);
+    SR_REQUIRE(momentum >= 0.f && momentum <= 1.f);
+    if (workspace_bytes < weightgen_ws_bytes(B, lp->cin, lp->cout)) return SR_ERR_WORKSPACE;
+    return weightgen_launch(dtype, B, pooled, pooled_ld, *lp, train, momentum, wdyn, wdyn_lo, (float*)workspace, (hipStream_t)stream);
 }

@@ -9,6 +9,8 @@ parameter holders only: `forward` packs the input to NHWC and calls the HIP kern
 (low-pass planes + pooled means, gates, per-sample weight generation, MFMA convolution).
 Only the default-kwargs configuration used by the owner scripts
 (train/train_realESRGAN_fdconv_1.py:85-91) is implemented; anything else raises NotImplementedError.
+In train() mode, or whenever autograd is recording on a float32 input, `forward` takes the differentiable path of
+super_resolution_amd/train.py (same forward kernels, BatchNorm on batch statistics in train(), HIP backward).
 """
 import ctypes as C
 import math
@@ -250,8 +252,10 @@ class FDConv(nn.Conv2d):
         `want`: optional dict that receives intermediates as torch tensors (tests only).
         """
         L.require_gpu(x, 'FDConv.forward')
-        if self.training and self.fdconv_active:
-            raise NotImplementedError('FDConv training (batch-statistics BatchNorm + backward) is not implemented yet')
+        if want is None and (self.training or (torch.is_grad_enabled() and x.dtype == torch.float32)):
+            # differentiable path (float32): batch-statistics BatchNorm in train() mode, hand-written backward kernels
+            from .train import conv_train
+            return conv_train(self, x)
         lib = L.lib()
         dt = x.dtype
         code = L.dtype_code(dt)
@@ -286,8 +290,10 @@ class FDConv(nn.Conv2d):
             # bf16: weights as hi + lo pairs (a rounded weight is an error coherent over the whole image)
             split = dt == torch.bfloat16
             wdyn = torch.empty(2 if split else 1, B, 9, cout, cin, dtype=dt, device=dev)
-            L.check(lib.sr_fdconv_weightgen(code, B, pooled.data_ptr(), cin, C.byref(lp), wdyn[0].data_ptr(),
-                                            wdyn[1].data_ptr() if split else None, st), 'sr_fdconv_weightgen')
+            mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout), dtype=torch.uint8, device=dev)
+            L.check(lib.sr_fdconv_weightgen(code, B, pooled.data_ptr(), cin, C.byref(lp), 0, 0.0, wdyn[0].data_ptr(),
+                                            wdyn[1].data_ptr() if split else None, mods.data_ptr(), mods.numel(), st),
+                    'sr_fdconv_weightgen')
             cc.bands = 1
             cc.l2[0], cc.l4[0], cc.l8[0] = L.view(bands[0]), L.view(bands[1]), L.view(bands[2])
             L.check(lib.sr_conv3x3(code, B, H, W, C.byref(cc), gates.data_ptr(), wdyn.data_ptr(), 9 * cout * cin,

@@ -102,7 +102,10 @@ class RealESRGANer():
         self.img = t
 
     def process(self):
-        self.output = self.model(self.img)
+        # inference only (the reference runs this under enhance()'s @torch.no_grad, utils.py:193): a caller that steps
+        # through pre_process / process / post_process by hand must not end up on the differentiable training path
+        with torch.no_grad():
+            self.output = self.model(self.img)
 
     def tile_windows(self):
         """(input window, output core, offset of the core inside the window) per tile, in the reference's loop order."""

@@ -1,0 +1,373 @@
+"""Differentiable train-mode path of RRDBNet-FDConv on libsr_amd (training step of the owner scripts).
+
+Reference: train/train_realESRGAN_fdconv_1.py:98-118 -- `model.train(); pred = model(wf); pred_up = F.interpolate(pred,
+(2048, 2048), 'bilinear'); loss = L1(pred_up, sr); loss.backward(); optimizer.step()` -- where the backward pass comes from
+torch autograd through FDConv.forward (FDConv.py:640-722) and basicsr's RRDBNet.
+
+Here every conv layer is a `torch.autograd.Function` whose forward AND backward are hand-written HIP kernels:
+
+  forward   low-pass planes + pooled means, gates, per-sample weights (KSM_Global's BatchNorm on the statistics of the
+            batch, running statistics updated in place -- `sr_fdconv_weightgen(train=1)`), convolution;
+  backward  weight gradient (`sr_conv3x3_wgrad`, per-sample for FDConv), operand gradient (`sr_conv3x3` with the transposed
+            weights), band-mix / gate backward (`sr_fbm_backward`, `sr_fbm_gates_backward`), and the three band branches
+            back through `sr_fbm_lowpass` (the box low-pass is self-adjoint).
+
+Two things stay on torch autograd (device tensors, no CPU path):
+  * the SMALL weight path -- pooled (B, Cin) -> W_b (B, 9, Cout, Cin): KSM_Global / KSM_Local / spectral scatter + irfft2
+    (a few hundred KB per layer).  Its backward is torch's, on a torch restatement (`dynamic_weight`) that is recomputed
+    in backward and fed the HIP weight gradient;
+  * the glue between layers in `rrdbnet_train_forward` (LeakyReLU, channel concat, residual adds, nearest 2x).
+Data-parallel training: `allreduce_gradients` (bucketed all-reduce of the parameter gradients over torch.distributed --
+RCCL on the GPUs; BatchNorm statistics stay local to a rank, as under the reference's nn.DataParallel,
+train/train_realESRGAN_fdconv_OST_1.py:238-246).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from .fdconv import FDConv
+
+BN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the small weight path as torch ops (backward glue)
+# ------------------------------------------------------------------------------------------------------------------
+def dynamic_weight(pooled, m, training):
+    """W_b (B, 9, Cout, Cin) of FDConv `m` from the pooled means (B, Cin): FDConv.py:643-652, 661-697.
+
+    Same result as `sr_fdconv_weightgen`, built from differentiable torch ops; used only to back-propagate the weight
+    gradient into the KSM / spectrum parameters and the pooled means."""
+    g, loc = m.KSM_Global, m.KSM_Local
+    B, cin = pooled.shape
+    cout = m.out_channels
+    z = F.linear(pooled, g.fc.weight.flatten(1))
+    if training:
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+    else:
+        mean, var = g.bn.running_mean, g.bn.running_var
+    z = (z - mean) / torch.sqrt(var + BN_EPS) * g.bn.weight + g.bn.bias
+    a = g.relu.scale * torch.relu(z) ** 2 + g.relu.bias
+    head = lambda fc: F.linear(a, fc.weight.flatten(1), fc.bias)
+    ca = 2.0 * torch.sigmoid(head(g.channel_fc))                       # (B, Cin)
+    fa = 2.0 * torch.sigmoid(head(g.filter_fc))                        # (B, Cout)
+    sa = 2.0 * torch.sigmoid(head(g.spatial_fc))                       # (B, 9)
+    ka = torch.sigmoid(head(g.kernel_fc)) * (2.0 / m.kernel_num)       # (B, kn)
+    ln = F.layer_norm(pooled, (cin,), loc.norm.weight, loc.norm.bias, 1e-5)
+    k = loc.conv.kernel_size[0]
+    logit = F.conv1d(ln[:, None, :], loc.conv.weight, padding=(k - 1) // 2)        # (B, Cout*9, Cin)
+    hr = 2.0 * torch.sigmoid(logit).view(B, cout, 9, cin)                          # [b, o, tap, i]
+    # spectrum scaled per frequency group and sample, inverse real 2-D DFT, (3Cout, 3Cin) -> [o, u, i, v]
+    spec = torch.view_as_complex(m.dft_weight[0].contiguous()) * float(m.alpha)    # (3Cout, 3Cin/2+1)
+    gmap = m.group_map().long()
+    per_bin = ka[:, gmap.view(-1)].view(B, *gmap.shape)                            # ka[b, G(r, c)]
+    adaptive = torch.fft.irfft2(spec[None] * per_bin, s=(3 * cout, 3 * cin))       # (B, 3Cout, 3Cin)
+    adaptive = adaptive.view(B, cout, 3, cin, 3).permute(0, 2, 4, 1, 3).reshape(B, 9, cout, cin)
+    return sa.view(B, 9, 1, 1) * ca.view(B, 1, 1, cin) * fa.view(B, 1, cout, 1) * hr.permute(0, 2, 1, 3) * adaptive
+
+
+_WEIGHT_PATH = ('dft_weight', 'KSM_Global.fc.weight', 'KSM_Global.bn.weight', 'KSM_Global.bn.bias', 'KSM_Global.relu.scale',
+                'KSM_Global.relu.bias', 'KSM_Global.channel_fc.weight', 'KSM_Global.channel_fc.bias',
+                'KSM_Global.filter_fc.weight', 'KSM_Global.filter_fc.bias', 'KSM_Global.spatial_fc.weight',
+                'KSM_Global.spatial_fc.bias', 'KSM_Global.kernel_fc.weight', 'KSM_Global.kernel_fc.bias',
+                'KSM_Local.conv.weight', 'KSM_Local.norm.weight', 'KSM_Local.norm.bias')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------------------------
+def _pack(x):
+    B, Cc, H, W = x.shape
+    xn = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
+    code = L.dtype_code(x.dtype)
+    L.check(L.lib().sr_pack_nchw(x.data_ptr(), code, xn.data_ptr(), code, B, Cc, H, W, 1, L.stream_ptr(x.device)), 'sr_pack_nchw')
+    return xn
+
+
+def _unpack(xn):
+    B, H, W, Cc = xn.shape
+    x = torch.empty(B, Cc, H, W, dtype=xn.dtype, device=xn.device)
+    code = L.dtype_code(xn.dtype)
+    L.check(L.lib().sr_unpack_nhwc(xn.data_ptr(), code, x.data_ptr(), code, B, Cc, H, W, L.stream_ptr(xn.device)), 'sr_unpack_nhwc')
+    return x
+
+
+def _concat1(xn, bands=None):
+    cc = L.Concat()
+    cc.nseg = 1
+    cc.x[0] = L.view(xn)
+    if bands is not None:
+        cc.bands = 1
+        cc.l2[0], cc.l4[0], cc.l8[0] = L.view(bands[0]), L.view(bands[1]), L.view(bands[2])
+    return cc
+
+
+def _conv(xn, cc, gates, w, w_bstride, cout, bias=None):
+    B, H, W, _ = xn.shape
+    yn = torch.empty(B, H, W, cout, dtype=xn.dtype, device=xn.device)
+    ep = L.Epilogue()
+    ep.bias = bias
+    L.check(L.lib().sr_conv3x3(L.dtype_code(xn.dtype), B, H, W, C.byref(cc), L.ptr(gates), w.data_ptr(), w_bstride, 0, cout,
+                               C.byref(ep), L.view(yn), L.stream_ptr(xn.device)), 'sr_conv3x3')
+    return yn
+
+
+def _check_input(x, who):
+    L.require_gpu(x, who)
+    if x.dtype != torch.float32:
+        raise TypeError('%s: the training path computes in float32 (got %s)' % (who, x.dtype))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------------------------
+class _PlainConvFn(torch.autograd.Function):
+    """nn.Conv2d(.,.,3,1,1): forward sr_conv3x3, backward sr_conv3x3_wgrad + sr_conv3x3 on the transposed weights."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _check_input(x, 'conv (train)')
+        lib, dev = L.lib(), x.device
+        cout, cin = weight.shape[:2]
+        with torch.cuda.device(dev):
+            xn = _pack(x.contiguous())
+            wp, _ = L.pack_plain_weight(weight.detach(), torch.float32, cout, cin)
+            yn = _conv(xn, _concat1(xn), None, wp, 0, cout, None if bias is None else bias.detach().data_ptr())
+            y = _unpack(yn)
+        ctx.save_for_backward(xn, wp)
+        ctx.has_bias = bias is not None
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, wp = ctx.saved_tensors
+        lib, dev = L.lib(), dy.device
+        B, H, W, cin = xn.shape
+        cout = dy.shape[1]
+        with torch.cuda.device(dev):
+            st = L.stream_ptr(dev)
+            dyn = _pack(dy.contiguous())
+            dw = torch.empty(9, cout, cin, dtype=torch.float32, device=dev)
+            db = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            cc = _concat1(xn)
+            L.check(lib.sr_conv3x3_wgrad(L.SR_F32, B, H, W, C.byref(cc), None, L.view(dyn), cout, 0, dw.data_ptr(), L.ptr(db), st),
+                    'sr_conv3x3_wgrad')
+            dx = None
+            if ctx.need_dx:
+                wt = torch.empty(9, cin, cout, dtype=torch.float32, device=dev)
+                L.check(lib.sr_conv_weight_transpose(wp.data_ptr(), wt.data_ptr(), L.SR_F32, 1, cout, cin, st), 'sr_conv_weight_transpose')
+                dx = _unpack(_conv(dyn, _concat1(dyn), None, wt, 0, cin))
+        return dx, dw.permute(1, 2, 0).reshape(cout, cin, 3, 3), db
+
+
+class _FDConvFn(torch.autograd.Function):
+    """An active FDConv layer.  Arguments after the module are its parameters in `named_parameters()` order (so that
+    autograd routes their gradients); the module supplies the derived buffers (basis, group map, FFT plan)."""
+
+    @staticmethod
+    def forward(ctx, x, m, training, *params):
+        _check_input(x, 'FDConv (train)')
+        lib, dev = L.lib(), x.device
+        B, cin, H, W = x.shape
+        cout = m.out_channels
+        if training and B < 2:
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                             % (torch.Size([B, m.KSM_Global.fc.out_channels, 1, 1]),))  # nn.BatchNorm2d's own error
+        with torch.cuda.device(dev):
+            st = L.stream_ptr(dev)
+            lp, _keep = m.sr_layer_params(torch.float32)
+            plan = m._plan(H, W)
+            xn = _pack(x.contiguous())
+            bands = [torch.empty_like(xn) for _ in range(3)]
+            pooled = torch.empty(B, cin, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
+            L.check(lib.sr_fbm_lowpass(plan, L.SR_F32, B, L.view(xn), 0, L.view(bands[0]), L.view(bands[1]), L.view(bands[2]),
+                                       pooled.data_ptr(), cin, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass')
+            gates = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+            cc = _concat1(xn)
+            L.check(lib.sr_fbm_gates(L.SR_F32, B, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st), 'sr_fbm_gates')
+            wdyn = torch.empty(B, 9, cout, cin, dtype=torch.float32, device=dev)
+            mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout), dtype=torch.uint8, device=dev)
+            bn = m.KSM_Global.bn
+            mom = 0.0
+            if training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            L.check(lib.sr_fdconv_weightgen(L.SR_F32, B, pooled.data_ptr(), cin, C.byref(lp), int(training), float(mom),
+                                            wdyn.data_ptr(), None, mods.data_ptr(), mods.numel(), st), 'sr_fdconv_weightgen')
+            yn = _conv(xn, _concat1(xn, bands), gates, wdyn, 9 * cout * cin, cout, lp.bias)
+            y = _unpack(yn)
+        ctx.m, ctx.training = m, training
+        ctx.names = [n for n, _ in m.named_parameters()]
+        ctx.save_for_backward(xn, bands[0], bands[1], bands[2], gates, pooled, wdyn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, b2, b4, b8, gates, pooled, wdyn = ctx.saved_tensors
+        m = ctx.m
+        lib, dev = L.lib(), dy.device
+        B, H, W, cin = xn.shape
+        cout = m.out_channels
+        grads = {}
+        with torch.cuda.device(dev):
+            st = L.stream_ptr(dev)
+            lp, _keep = m.sr_layer_params(torch.float32)
+            plan = m._plan(H, W)
+            dyn = _pack(dy.contiguous())
+            # 1. weight / bias gradients of the convolution
+            dw = torch.empty(B, 9, cout, cin, dtype=torch.float32, device=dev)
+            db = torch.empty(cout, dtype=torch.float32, device=dev) if m.bias is not None else None
+            cc = _concat1(xn, (b2, b4, b8))
+            L.check(lib.sr_conv3x3_wgrad(L.SR_F32, B, H, W, C.byref(cc), gates.data_ptr(), L.view(dyn), cout, 1, dw.data_ptr(),
+                                         L.ptr(db), st), 'sr_conv3x3_wgrad')
+            if db is not None:
+                grads['bias'] = db
+            # 2. gradient wrt the modulated operand: convolution of dy with the transposed, mirrored weights
+            wt = torch.empty(B, 9, cin, cout, dtype=torch.float32, device=dev)
+            L.check(lib.sr_conv_weight_transpose(wdyn.data_ptr(), wt.data_ptr(), L.SR_F32, B, cout, cin, st), 'sr_conv_weight_transpose')
+            da = _conv(dyn, _concat1(dyn), None, wt, 9 * cin * cout, cin)
+            # 3. band mix: four linear branches + gate logits
+            dxd, dl2, dl4, dl8 = (torch.empty_like(xn) for _ in range(4))
+            dz = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+            L.check(lib.sr_fbm_backward(L.SR_F32, B, H, W, L.view(xn), L.view(b2), L.view(b4), L.view(b8), gates.data_ptr(), L.view(da),
+                                        L.view(dxd), L.view(dl2), L.view(dl4), L.view(dl8), dz.data_ptr(), st), 'sr_fbm_backward')
+            # 4. the band branches back through the (self-adjoint) low-pass: plane k of lowpass(dl_k)
+            ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
+            adj = []
+            scratch = [torch.empty_like(xn), torch.empty_like(xn)]
+            for k, src in enumerate((dl2, dl4, dl8)):
+                out = torch.empty_like(xn)
+                planes = [scratch[0], scratch[1]]
+                planes.insert(k, out)
+                L.check(lib.sr_fbm_lowpass(plan, L.SR_F32, B, L.view(src), 0, L.view(planes[0]), L.view(planes[1]), L.view(planes[2]),
+                                           None, 0, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass (adjoint)')
+                adj.append(out)
+            # 5. the small weight path on torch autograd: dW_b -> parameters and pooled means
+            params = dict(m.named_parameters())
+            wp = [params[n] for n in _WEIGHT_PATH]
+            with torch.enable_grad():
+                pl = pooled.detach().requires_grad_(True)
+                wfull = dynamic_weight(pl, m, ctx.training)
+                got = torch.autograd.grad(wfull, [pl] + wp, dw, allow_unused=True)
+            dpooled = got[0].contiguous()
+            for n, gch in zip(_WEIGHT_PATH, got[1:]):
+                grads[n] = gch
+            # 6. gate convs + assembly of the input gradient
+            dgw = torch.empty(3, cin, 9, dtype=torch.float32, device=dev)
+            dgb = torch.empty(3, dtype=torch.float32, device=dev)
+            dxn = torch.empty_like(xn)
+            L.check(lib.sr_fbm_gates_backward(L.SR_F32, B, H, W, L.view(xn), dz.data_ptr(), C.byref(lp), L.view(dxd), L.view(adj[0]),
+                                              L.view(adj[1]), L.view(adj[2]), dpooled.data_ptr(), cin, L.view(dxn), dgw.data_ptr(),
+                                              dgb.data_ptr(), st), 'sr_fbm_gates_backward')
+            for k in range(3):
+                grads['FBM.freq_weight_conv_list.%d.weight' % k] = dgw[k].reshape(1, cin, 3, 3)
+                grads['FBM.freq_weight_conv_list.%d.bias' % k] = dgb[k:k + 1]
+            dx = _unpack(dxn) if ctx.needs_input_grad[0] else None
+        return (dx, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+def conv_train(m, x):
+    """One conv layer of the network on the differentiable path: FDConv (active or thin) or nn.Conv2d, 3x3 / 1 / 1."""
+    if isinstance(m, FDConv) and m.fdconv_active:
+        return _FDConvFn.apply(x, m, m.training, *[p for _, p in m.named_parameters()])
+    if m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1) or m.groups != 1 or m.dilation != (1, 1):
+        raise NotImplementedError('libsr_amd implements 3x3 / stride 1 / padding 1 convolutions')
+    return _PlainConvFn.apply(x, m.weight, m.bias)
+
+
+def rrdbnet_train_forward(net, x):
+    """RRDBNet.forward (basicsr rrdbnet_arch.py; call site train/train_realESRGAN_fdconv_1.py:114) with an autograd graph."""
+    _check_input(x, 'RRDBNet (train)')
+    lrelu = lambda t: F.leaky_relu(t, 0.2)
+    if net.scale == 2:
+        x = F.pixel_unshuffle(x, 2)
+    elif net.scale == 1:
+        x = F.pixel_unshuffle(x, 4)
+    feat = conv_train(net.conv_first, x)
+    body = feat
+    for blk in net.body:
+        blk_in = body
+        for rdb in (blk.rdb1, blk.rdb2, blk.rdb3):
+            x0 = body
+            x1 = lrelu(conv_train(rdb.conv1, x0))
+            x2 = lrelu(conv_train(rdb.conv2, torch.cat((x0, x1), 1)))
+            x3 = lrelu(conv_train(rdb.conv3, torch.cat((x0, x1, x2), 1)))
+            x4 = lrelu(conv_train(rdb.conv4, torch.cat((x0, x1, x2, x3), 1)))
+            x5 = conv_train(rdb.conv5, torch.cat((x0, x1, x2, x3, x4), 1))
+            body = x5 * 0.2 + x0
+        body = body * 0.2 + blk_in
+    feat = feat + conv_train(net.conv_body, body)
+    feat = lrelu(conv_train(net.conv_up1, F.interpolate(feat, scale_factor=2, mode='nearest')))
+    feat = lrelu(conv_train(net.conv_up2, F.interpolate(feat, scale_factor=2, mode='nearest')))
+    return conv_train(net.conv_last, lrelu(conv_train(net.conv_hr, feat)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# data-parallel gradient exchange
+# ------------------------------------------------------------------------------------------------------------------
+def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20, average=True):
+    """Sum (or average) `.grad` of the parameters over the ranks of `group`: the one exchange of data-parallel training
+    (reference: nn.DataParallel's gradient reduction, train/train_realESRGAN_fdconv_OST_1.py:238-246).
+
+    Gradients are flattened into buckets of `bucket_bytes` (~25 MB: 82 MB of RRDBNet-FDConv gradients -> 4 all-reduces
+    per step, each long enough to run at the xGMI link rate), every bucket's all-reduce is issued asynchronously and the
+    results are scattered back once all have completed.  Parameters without a gradient count as zeros so that every rank
+    issues the same collectives.  BatchNorm running statistics are NOT exchanged (local statistics, like the reference)."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return 0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    params = [p for p in parameters if p.requires_grad]
+    buckets, cur, size = [], [], 0
+    for p in params:
+        nbytes = p.numel() * p.element_size()
+        if cur and (size + nbytes > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(p)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    work = []
+    for bucket in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        work.append((bucket, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    for bucket, flat, handle in work:
+        handle.wait()
+        if average:
+            flat /= world
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            piece = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = piece.clone()
+            else:
+                p.grad.copy_(piece)
+            off += n
+    return len(buckets)
+
+
+def train_step(net, optimizer, wf, sr, weighted=False, sigmoid=False, clip_grad_norm=None, group=None):
+    """One optimisation step shaped as train/train_realESRGAN_fdconv_1.py:113-118 (weighted / sigmoid / clip: the variants of
+    train/train_realESRGAN_fdconv.py:107-142): forward, bilinear resize to the target size + L1 (one fused HIP kernel that
+    also returns d loss / d pred), backward, gradient all-reduce when torch.distributed is initialised, optimizer step.
+    Returns the loss (a 0-d device tensor)."""
+    from .head import resize_l1_loss
+    net.train()
+    optimizer.zero_grad()
+    pred = net(wf)
+    loss = resize_l1_loss(pred, sr, weighted=weighted, sigmoid=sigmoid)
+    loss.backward()
+    allreduce_gradients(net.parameters(), group=group)
+    if clip_grad_norm is not None:
+        nn.utils.clip_grad_norm_(net.parameters(), clip_grad_norm)
+    optimizer.step()
+    return loss.detach()

@@ -58,3 +58,45 @@ def test_tile_sharding_world2_matches_single_process():
     oks = [r[0] for r in res if r[0] is not None]
     assert oks == [True]
     assert sum(r[2] for r in res) == res[0][1] == 12  # 3 x 4 tiles, every tile computed exactly once
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from super_resolution_amd.train import allreduce_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 3, 3, padding=1))
+    frozen = torch.nn.Parameter(torch.ones(5))  # a parameter that never receives a gradient on rank 1
+    params = list(net.parameters()) + [frozen]
+    data = torch.randn(4, 3, 6, 6, generator=torch.Generator().manual_seed(10))  # global batch; each rank takes its half
+    x = data[2 * rank:2 * rank + 2]
+    loss = net(x).square().mean() + (frozen.sum() if rank == 0 else 0.0)
+    loss.backward()
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    nb = allreduce_gradients(params, bucket_bytes=600)  # tiny buckets: several collectives
+    gathered = [torch.zeros(sum(p.numel() for p in params)) for _ in range(world)]
+    mine = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(local, params)])
+    dist.all_gather(gathered, mine)
+    want = sum(gathered) / world
+    got = torch.cat([p.grad.reshape(-1) for p in params])
+    # BatchNorm statistics stay local: the two ranks saw different halves of the batch
+    q.put((rank, bool(torch.allclose(got, want, atol=1e-7)), nb, net[1].running_mean.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_averages_and_keeps_bn_local():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2] and res[0][2] >= 3  # the same number of collectives on both ranks, several buckets
+    assert not torch.allclose(res[0][3], res[1][3])   # running statistics differ: not exchanged

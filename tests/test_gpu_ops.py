@@ -349,9 +349,58 @@ def test_basis_and_weightgen(L, cin, cout):
         torch.einsum('bg,goiuv->boiuv', ka, ref_b) * hr
     wd = torch.empty(B, 9, cout, cin, device='cuda:0')
     pd = dev(pooled)
-    L.check(lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), wd.data_ptr(), None, st(L)))
+    mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout) // 4, device='cuda:0')
+    L.check(lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), 0, 0.0, wd.data_ptr(), None, mods.data_ptr(),
+                                    mods.numel() * 4, st(L)))
     got_w = wd.cpu().view(B, 3, 3, cout, cin).permute(0, 3, 4, 1, 2)
     assert (got_w - ref_w).abs().max().item() < 2e-6 * max(1.0, ref_w.abs().max().item())
+    # the modulation vectors left in the workspace: ca | ln | fa | sa | ka
+    ms = (2 * cin + cout + 13 + 3) & ~3  # sample stride in floats (include/sr_amd.h)
+    m = mods.cpu()[:B * ms].view(B, ms)
+    assert (m[:, :cin] - ca).abs().max().item() < 2e-6
+    assert (m[:, 2 * cin:2 * cin + cout] - fa).abs().max().item() < 2e-6
+    assert (m[:, 2 * cin + cout:2 * cin + cout + 9] - sa).abs().max().item() < 2e-6
+    assert (m[:, 2 * cin + cout + 9:2 * cin + cout + 13] - ka).abs().max().item() < 2e-6
+    # a workspace that is too small is refused before anything is launched
+    assert lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), 0, 0.0, wd.data_ptr(), None, mods.data_ptr(), 16, st(L)) == -2
+
+
+@pytest.mark.parametrize('cin,cout,B', [(64, 32, 4), (192, 64, 2), (96, 32, 33)])
+def test_weightgen_train_mode_batch_statistics(L, cin, cout, B):
+    """Train-mode KSM_Global: BatchNorm over the batch of pooled vectors (FDConv.py:245-258 under model.train()), running
+    statistics updated in place (momentum 0.1, unbiased variance), against the oracle's train-mode restatement."""
+    lib = L.lib()
+    keep = []
+    sd = gp.fdconv_params(cin, cout, 23)
+    lp, basis = make_lp(L, sd, cin, cout, torch.float32, keep)
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    pooled = torch.from_numpy(gp.signed_input((B, cin), 24))
+    ca, fa, sa, ka = fr.ksm_global(pooled, t, training=True)
+    hr = fr.ksm_local(pooled, t, cout)
+    ref_b = fr.spectral_bases(t['dft_weight'], fr.freq_group_map(cout, cin), fr.fdconv_alpha(cout, cin), cout, cin).float()
+    ref_w = sa.view(B, 1, 1, 3, 3) * ca.view(B, 1, cin, 1, 1) * fa.view(B, cout, 1, 1, 1) * \
+        torch.einsum('bg,goiuv->boiuv', ka, ref_b) * hr
+    z = pooled @ t['KSM_Global.fc.weight'].flatten(1).t()
+    rm_ref = 0.9 * t['KSM_Global.bn.running_mean'] + 0.1 * z.mean(0)
+    rv_ref = 0.9 * t['KSM_Global.bn.running_var'] + 0.1 * z.var(0, unbiased=True)
+    bn = torch.nn.BatchNorm2d(16).train()  # torch's own update rule as a cross-check of the two lines above
+    bn.running_mean.copy_(t['KSM_Global.bn.running_mean'])
+    bn.running_var.copy_(t['KSM_Global.bn.running_var'])
+    bn(z.view(B, 16, 1, 1))
+    assert (bn.running_mean - rm_ref).abs().max().item() < 1e-6 and (bn.running_var - rv_ref).abs().max().item() < 1e-6
+    wd = torch.empty(B, 9, cout, cin, device='cuda:0')
+    pd = dev(pooled)
+    mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout) // 4, device='cuda:0')
+    L.check(lib.sr_fdconv_weightgen(0, B, pd.data_ptr(), cin, C.byref(lp), 1, 0.1, wd.data_ptr(), None, mods.data_ptr(),
+                                    mods.numel() * 4, st(L)))
+    got_w = wd.cpu().view(B, 3, 3, cout, cin).permute(0, 3, 4, 1, 2)
+    assert (got_w - ref_w).abs().max().item() < 3e-6 * max(1.0, ref_w.abs().max().item())
+    rm, rv = keep[0]['KSM_Global.bn.running_mean'].cpu(), keep[0]['KSM_Global.bn.running_var'].cpu()
+    assert (rm - rm_ref).abs().max().item() < 1e-6 * max(1.0, rm_ref.abs().max().item())
+    assert (rv - rv_ref).abs().max().item() < 1e-6 * max(1.0, rv_ref.abs().max().item())
+    # one value per channel: torch raises in train mode, the library refuses
+    assert lib.sr_fdconv_weightgen(0, 1, pd.data_ptr(), cin, C.byref(lp), 1, 0.1, wd.data_ptr(), None, mods.data_ptr(),
+                                   mods.numel() * 4, st(L)) == -1
 
 
 # ------------------------------------------------------------------------------------------ conv

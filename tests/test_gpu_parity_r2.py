@@ -310,12 +310,17 @@ def test_tile_batching_with_dynamic_weights(sra):
     assert (outs[0][:, :, y0 * 4:y1 * 4, x0 * 4:x1 * 4] - ref).abs().max().item() < FP32_TOL
 
 
-def test_train_mode_forward_refuses_to_run_without_autograd(sra):
+def test_train_mode_forward_records_an_autograd_graph(sra):
+    """a train()-mode forward must never hand back a tensor without grad_fn (tests/test_gpu_train.py
+    checks the gradients themselves)."""
     net = sra.RRDBNet(3, 3, 4, 8, 1, 4).cuda()  # modules are born in train() mode
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 3, 8, 8, device='cuda'))
+    y = net(torch.zeros(1, 3, 8, 8, device='cuda'))
+    assert y.grad_fn is not None and y.shape == (1, 3, 32, 32)
+    with pytest.raises(TypeError):  # the differentiable path computes in float32
+        net(torch.zeros(1, 3, 8, 8, device='cuda', dtype=torch.bfloat16))
+    net.eval()
     with torch.no_grad():
-        assert net(torch.zeros(1, 3, 8, 8, device='cuda')).shape == (1, 3, 32, 32)  # plain net, no_grad: same as eval
+        assert net(torch.zeros(1, 3, 8, 8, device='cuda')).grad_fn is None  # executor path
 
 
 def test_dni_and_checkpoint_containers(sra, tmp_path):

@@ -152,3 +152,46 @@ def test_enhance_modes():
     assert o.shape == (24, 20, 4) and m == 'RGBA'
     o, m = rr.enhance(net, gp.image_input((6, 5, 4), 3), 4, pre_pad=0, alpha_upsampler=None)
     assert o.shape == (24, 20, 4) and m == 'RGBA'
+
+
+@pytest.mark.parametrize('tag,cin,cout,B,h,w,pseed', [('c64_32', 64, 32, 4, 20, 24, 100), ('c192_64', 192, 64, 2, 16, 12, 104)])
+def test_oracle_train_mode_gradients_vs_reference(golden_r2, tag, cin, cout, B, h, w, pseed):
+    """Pins the oracle's BACKWARD (torch autograd through the restatement, train-mode BatchNorm) to the reference's
+    gradients of loss = sum(y * r) wrt the input and every parameter."""
+    g = golden_r2['fdconv_train_grads']
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+          for k, v in t(gp.fdconv_params(cin, cout, seed=pseed)).items()}
+    x = torch.from_numpy(gp.signed_input((B, cin, h, w), seed=300)).requires_grad_(True)
+    y = fr.fdconv_forward(x, sd, training=True)
+    r = torch.from_numpy(gp.signed_input(tuple(y.shape), 301))
+    (y * r).sum().backward()
+    assert np.abs(y.detach().numpy() - g[tag + '.y']).max() < FP32_TOL * max(1.0, np.abs(g[tag + '.y']).max())
+    checked = 0
+    for key in g.files:
+        if not key.startswith(tag + '.grad.'):
+            continue
+        name = key[len(tag) + 6:]
+        got = x.grad if name == 'x' else sd[name].grad
+        ref = g[key]
+        assert got is not None, name
+        assert np.abs(got.numpy() - ref).max() <= FP32_TOL * max(1.0, np.abs(ref).max()), name
+        checked += 1
+    assert checked == 25  # input + 24 parameters
+
+
+def test_training_glue_dynamic_weight_matches_oracle():
+    """super_resolution_amd.train.dynamic_weight (the torch restatement of the small weight path that the HIP backward
+    hands its weight gradient to) against the oracle's weights, eval and train mode, on the CPU."""
+    import super_resolution_amd as sra
+    for cin, cout, seed in ((64, 32, 100), (192, 64, 104)):
+        sd = t(gp.fdconv_params(cin, cout, seed=seed))
+        m = sra.FDConv(cin, cout, kernel_size=3, stride=1, padding=1, bias=True)
+        m.load_state_dict(sd, strict=True)
+        x = torch.from_numpy(gp.signed_input((3, cin, 8, 8), seed=5))
+        for training in (False, True):
+            want = {}
+            fr.fdconv_forward(x, sd, training=training, want=want)
+            with torch.no_grad():
+                w = sra.train.dynamic_weight(want['pooled'], m, training)
+            ref = want['weight'].permute(0, 3, 4, 1, 2).reshape(3, 9, cout, cin)
+            assert (w - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
