@@ -3,6 +3,8 @@
 
     python bench.py --gpus 1 --steps 5 --warmup 2                    # BASELINE.json configs[1] (the metric's config)
     python bench.py --config tiled --steps 1 --warmup 1              # BASELINE.json configs[2]: 4096^2 tiled image
+    python bench.py --config train --steps 2 --warmup 1              # BASELINE.json configs[3]: training step (fp32)
+    python bench.py --config srvgg                                   # BASELINE.json configs[4]: SRVGGNetCompact 1080p
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W [--config tiled]
 
@@ -350,13 +352,78 @@ def run_srvgg(args, world, rank, dev, dist):
     return res
 
 
+def run_train(args, world, rank, dev, dist):
+    """BASELINE.json configs[3]: one optimisation step of RRDBNet-FDConv(1,1,64,23,32) shaped as
+    train/train_realESRGAN_fdconv_1.py:110-118 -- forward in train() mode, bilinear resize to the HR size + L1, backward,
+    gradient all-reduce over the ranks (RCCL), Adam -- on `--train-batch` HR crops of 256x256 per GPU (LR = 4x area
+    downsample), float32 (stage 1 of the training path: fp32 kernels, no MFMA yet).  The perceptual (VGG19) term of the
+    Real-ESRGAN recipe is basicsr framework code outside SURVEY section 8 and is not part of the owner's script."""
+    from super_resolution_amd import RRDBNet, replace_conv_with_fdconv, train as T
+    # the network as the owner script builds it (train_realESRGAN_fdconv_1.py:100-102): RRDBNet's own initialisation, every
+    # conv swapped for a freshly initialised FDConv.  (The O(1)-perturbed parameter set of the inference configs makes the
+    # 23-block network chaotic -- DESIGN.md -- and its gradients overflow float32 after two Adam steps.)
+    torch.manual_seed(1234)
+    net = replace_conv_with_fdconv(RRDBNet(1, 1, 4, NUM_FEAT, NUM_BLOCK, NUM_GROW)).to(dev)
+    net.train()
+    B, hr = args.train_batch, args.train_hr
+    lr_side = hr // 4
+    g = torch.Generator().manual_seed(4321 + rank)
+    sr = synthetic_batch(B, hr, hr, 'cpu', seed=4321 + rank)
+    sr = sr * torch.linspace(0.3, 1.0, B, dtype=torch.float32).view(B, 1, 1, 1)  # crops of different brightness
+    wf = torch.nn.functional.avg_pool2d(sr, 4)
+    sr, wf = sr.to(dev), wf.to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    losses = []
+    for _ in range(max(args.warmup, 1)):
+        losses.append(float(T.train_step(net, opt, wf, sr)))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = T.train_step(net, opt, wf, sr)
+    sync()
+    elapsed = time.perf_counter() - t0
+    losses.append(float(loss))
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    step_s = float(tmax) / args.steps
+    nparam = sum(p.numel() for p in net.parameters())
+    flops = 3 * 2.0 * conv_macs_per_lr_pixel(1, 1) * B * lr_side * lr_side  # forward + operand gradient + weight gradient
+    return {
+        'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
+        'value': world * B * hr * hr / 1e6 / step_s, 'unit': 'output Mpix/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': max(args.warmup, 1), 'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'training step of RRDBNet-FDConv(1,1,64,23,32): %d HR crops of %dx%d per GPU (LR %dx%d), train-mode '
+                               'forward + bilinear/L1 loss + backward + gradient all-reduce + Adam, float32 '
+                               '(BASELINE.json configs[3], L1 term of the owner script)' % (B, hr, hr, lr_side, lr_side),
+                   'global_batch': world * B, 'samples_per_s': world * B / step_s,
+                   'parallelism': 'data parallel x%d, bucketed gradient all-reduce of %.1f M parameters (local BatchNorm statistics)' % (world, nparam / 1e6),
+                   'loss_first_last': [losses[0], losses[-1]], 'loss_finite': bool(np.isfinite(losses).all()),
+                   'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9},
+        'roofline': {'bound': 'mfma', 'kernel': 'conv forward + operand gradient + weight gradient (fp32 VALU kernels in this stage)',
+                     'achieved': flops / step_s / 1e12, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'note': 'whole-step time (no per-kernel events in the training path yet); algorithmic conv FLOPs = 3 x forward'},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', choices=('batch', 'tiled', 'srvgg'), default='batch')
+    ap.add_argument('--config', choices=('batch', 'tiled', 'srvgg', 'train'), default='batch')
     ap.add_argument('--frames', type=int, default=4, help='srvgg: 1080p frames per step')
+    ap.add_argument('--train-batch', type=int, default=32, help='train: HR crops per GPU and step')
+    ap.add_argument('--train-hr', type=int, default=256, help='train: side of the HR crops')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')
@@ -389,7 +456,7 @@ def main():
     if args.no_split_weights:
         from super_resolution_amd import _lib
         _lib.lib().sr_debug_split_weights(0)
-    res = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch}[args.config](args, world, rank, dev, dist)
+    res = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch, 'train': run_train}[args.config](args, world, rank, dev, dist)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

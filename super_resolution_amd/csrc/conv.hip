@@ -167,6 +167,11 @@ __device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, f
 //   waves 0-3 (MFMA)     run the 9 taps x 2 k-steps of the current chunk out of the other stage.
 // One barrier per chunk; the chunk time is max(HBM stream, MFMA), i.e. the kernel runs at whichever
 // roofline the layer is on (the banded FDConv operand is 4 tensors wide -> HBM).
+// timing experiment (DBG == 6): cycles of workgroup 0's first consumer / first loader wave
+//   0 consumer wait at the chunk barrier, 1 hi multiply, 2 wait at the mid barrier, 3 lo multiply, 4 epilogue (+ tile setup)
+//   5 loader stage_chunk, 6 loader wait at the chunk barrier, 7 chunks
+__device__ unsigned long long g_dbg_cycles[8];
+
 struct ChunkCursor {  // walks the virtual concat in 32-channel chunks
     int s, cc, kc;
 };
@@ -175,137 +180,6 @@ struct ChunkCursor {  // walks the virtual concat in 32-channel chunks
 // (s_waitcnt vmcnt(0)): at the barrier in the middle of a chunk that would empty the loaders' two-deep load pipeline
 // once more per chunk (measured: +20 % conv time).  The data handed over at that barrier is LDS data only.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Where a chunk's weight slab comes from: sample base (+ low-order offset), first concat channel, first output channel.
-struct WRef {
-    const bf16_t* base;
-    int kc, o_blk;
-};
-
-// Stages one 32-channel chunk: the haloed pixel tile into lds_px and weight slabs into LDS.
-// Split weights: the per-sample weights are kept as two bf16 numbers, w = hi + lo (lo = bf16(w - hi)) -- the rounding of
-// the dynamic weights, an error that is coherent over the whole image, was the dominant bf16 error of a deep network
-// (finding 15) -- and the consumers multiply by both parts.
-//   SPLIT = 0: slab `whi` -> lds_wa, after the pixel rounds (the slab buffers alternate with the pixel stages).
-//   SPLIT = 1: (MT = 2: four slabs do not fit LDS) the consumers run every chunk twice, once per part, out of ONE pixel
-//              stage.  Slab buffers: lds_wa holds hi parts, lds_wb lo parts.  The low part of the PREVIOUS chunk
-//              (`wlo`) is written first, then comes the workgroup barrier that separates the consumers' hi and lo
-//              half-steps of that chunk (mid_barrier; skipped for the very first chunk), then the rest of the pixels
-//              and the high part of this chunk.
-//   SPLIT = 2: (MT = 1) both parts of THIS chunk (`whi`, `wlo`) go to lds_wa / lds_wb after the pixel rounds; the
-//              consumers issue two MFMAs per pixel fragment.  One barrier per chunk as without the split.
-template <int MT, bool BANDS, int SPLIT>
-__device__ __forceinline__ void stage_chunk(const Concat& in, const ChunkCursor& cur, int b, int H, int W, int h0, int w0,
-                                            const float* __restrict__ gates, const WRef whi, const WRef wlo,
-                                            bool mid_barrier, int cin, int cout, char* lds_px, char* lds_wa, char* lds_wb,
-                                            int ltid) {
-    const View vx = in.x[cur.s];
-    const int Ws = W >> in.ups;
-    const bf16_t* xb = (const bf16_t*)vx.p + (long)b * vx.bs;
-    const bool blocked = vx.ld == 8;
-    // ---- haloed pixel tile: 612 pixels x 4 slots of 8 channels ---------------------------------------
-    // G items per thread are fetched before any is consumed: the loaders are the only waves with loads in
-    // flight on this CU, so each must keep ~20 x 16 B outstanding to cover the HBM latency.
-    constexpr int G = BANDS ? 2 : 5;
-    const View v2 = in.l2[cur.s], v4 = in.l4[cur.s], v8 = in.l8[cur.s];
-    const bf16_t* b2 = BANDS ? (const bf16_t*)v2.p + (long)b * v2.bs : nullptr;
-    const bf16_t* b4 = BANDS ? (const bf16_t*)v4.p + (long)b * v4.bs : nullptr;
-    const bf16_t* b8 = BANDS ? (const bf16_t*)v8.p + (long)b * v8.bs : nullptr;
-    const float4* gb = (const float4*)gates + (long)b * H * W;
-    // ---- weight slabs: rows (tap, o) x 32 channels (L2-resident); issued first so that their latency hides behind
-    // the pixel rounds
-    constexpr int WITEMS = 9 * MT * 32 * 4;
-    constexpr int WG = (WITEMS + 255) / 256;
-    auto wload = [&](const WRef& r, uint4 (&wv)[WG]) {
-#pragma unroll
-        for (int g = 0; g < WG; ++g) {
-            const int it = ltid + g * 256;
-            const int chunk = it & 3, row = it >> 2;
-            const int tap = row / (MT * 32), o = row - tap * (MT * 32);
-            const int tapc = min(tap, 8), oc = min(r.o_blk + o, cout - 1);
-            wv[g] = *(const uint4*)(r.base + ((long)tapc * cout + oc) * cin + r.kc + chunk * 8);
-            if (r.o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    };
-    auto wstore = [&](const uint4 (&wv)[WG], char* lds_w) {
-#pragma unroll
-        for (int g = 0; g < WG; ++g) {
-            const int it = ltid + g * 256;
-            if (it < WITEMS) *(uint4*)(lds_w + swz(it >> 2, it & 3)) = wv[g];
-        }
-    };
-    uint4 wv_lo[WG], wv_hi[WG];
-    if (SPLIT) wload(wlo, wv_lo);  // unconditional (SPLIT = 1: a valid dummy reference for the first chunk): no branch around loads
-    wload(whi, wv_hi);
-    // Rounds of G items per thread, software-pipelined two deep: round r + 1 is in flight while round r is modulated
-    // and written to LDS, so the memory pipe never runs dry between rounds (the loaders are the only waves of the CU
-    // with global loads in flight, and they never store: the compiler can count their loads exactly).
-    constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
-    constexpr int RA = ROUNDS / 2;  // rounds ahead of the mid barrier (SPLIT = 1)
-    struct Batch {
-        uint4 vx[G], a2[G], a4[G], a8[G];
-        float4 gg[G];
-    };
-    auto locate = [&](int it, int& chunk, int& pi, int& h, int& w) {
-        if (blocked) {  // a channel block's pixels are contiguous: pixels fastest
-            chunk = it / NPIX;
-            pi = it - chunk * NPIX;
-        } else {  // NHWC: the 4 slots of a pixel are contiguous
-            chunk = it & 3;
-            pi = it >> 2;
-        }
-        const int py = pi / PW, px = pi - py * PW;
-        h = h0 + py - 1;
-        w = w0 + px - 1;
-    };
-    auto issue = [&](int r, Batch& bt) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            int chunk, pi, h, w;
-            locate(ltid + (r * G + g) * 256, chunk, pi, h, w);
-            // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards:
-            // a branch around a load makes hipcc drain the memory pipeline per element
-            const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
-            const int ch = cur.cc + (chunk & 3) * 8;
-            const unsigned ps = (unsigned)(hc >> in.ups) * Ws + (wc >> in.ups);
-            bt.vx[g] = *(const uint4*)(xb + voff32(vx, ps, ch));
-            if (BANDS) {
-                const unsigned p = (unsigned)hc * W + wc;
-                bt.a2[g] = *(const uint4*)(b2 + voff32(v2, p, ch));
-                bt.a4[g] = *(const uint4*)(b4 + voff32(v4, p, ch));
-                bt.a8[g] = *(const uint4*)(b8 + voff32(v8, p, ch));
-                bt.gg[g] = gb[p];
-            }
-        }
-    };
-    auto consume = [&](int r, const Batch& bt) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int it = ltid + (r * G + g) * 256;
-            int chunk, pi, h, w;
-            locate(it, chunk, pi, h, w);
-            uint4 v = bt.vx[g];
-            if (BANDS) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
-            if (!(h >= 0 && h < H && w >= 0 && w < W)) v = make_uint4(0u, 0u, 0u, 0u);
-            if (it < NPIX * 4) *(uint4*)(lds_px + swz(pi, chunk)) = v;
-        }
-    };
-    Batch bt0, bt1;
-    issue(0, bt0);
-    if (SPLIT == 1 && mid_barrier) wstore(wv_lo, lds_wb);  // the consumers are in the hi half-step of the previous chunk
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        if (SPLIT == 1 && r == RA && mid_barrier) lds_barrier();  // lo part of the previous chunk is in place
-        if (r + 1 < ROUNDS) {
-            if (r & 1) issue(r + 1, bt0);
-            else issue(r + 1, bt1);
-        }
-        if (r & 1) consume(r, bt1);
-        else consume(r, bt0);
-    }
-    wstore(wv_hi, lds_wa);
-    if (SPLIT == 2) wstore(wv_lo, lds_wb);
-}
 
 __device__ __forceinline__ bool advance(const Concat& in, ChunkCursor& cur) {
     cur.cc += 32;
@@ -353,7 +227,7 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
 //   SPLIT 1   : loaders  [lo(s-1), pixels A] -> barrier_{2s-1} -> [pixels B, hi(s)] -> barrier_{2s}; after the last chunk
 //               lo(last) -> barrier;          consumers  barrier_{2s} -> hi(s) -> barrier_{2s+1} -> lo(s)
 // LDS: two pixel stages, then the slabs: SPLIT 0: [stage 0][stage 1]; SPLIT 1: [hi][lo]; SPLIT 2: [s0 hi][s0 lo][s1 hi][s1 lo].
-template <int MT, bool BANDS, int SPLIT>
+template <int MT, bool BANDS, int SPLIT, int DBG = 0>
 __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, long w_lo_off,
                                                          int cin, int cout, Epilogue ep, View out, unsigned total) {
@@ -374,51 +248,175 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
     if (walk.next >= walk.end) return;  // whole workgroup: no barrier is skipped by a subset of waves
 
     if (loader) {
-        // ---- producer waves: never touch the accumulators (separate register budget).  They run one chunk
-        // ahead of the MFMA waves across tile boundaries, so a tile's first chunk streams in while the previous
-        // tile is still being multiplied and written out.
-        unsigned step = 0;
-        WRef prev{wts, 0, 0};
-        for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
-            const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
-            const bf16_t* wb = wts + (long)t.b * w_bstride;
-            ChunkCursor cur{0, 0, 0};
-            for (int c = 0; c < nchunks; ++c) {
-                const WRef whi{wb, cur.kc, t.o_blk};
-                char* px = lds + (step & 1) * STAGE_PX;
-                if (SPLIT == 1) {
-                    const WRef wlo{prev.base + w_lo_off, prev.kc, prev.o_blk};
-                    stage_chunk<MT, BANDS, 1>(in, cur, t.b, H, W, t.h0, t.w0, gates, whi, step ? wlo : whi, step != 0, cin,
-                                              cout, px, lds_wa, lds_wb, tid - 256);
-                } else if (SPLIT == 2) {
-                    const WRef wlo{wb + w_lo_off, cur.kc, t.o_blk};
-                    char* slab = lds_wa + (step & 1) * 2 * WSLAB;
-                    stage_chunk<MT, BANDS, 2>(in, cur, t.b, H, W, t.h0, t.w0, gates, whi, wlo, false, cin, cout, px, slab,
-                                              slab + WSLAB, tid - 256);
-                } else {
-                    stage_chunk<MT, BANDS, 0>(in, cur, t.b, H, W, t.h0, t.w0, gates, whi, whi, false, cin, cout, px,
-                                              (step & 1) ? lds_wb : lds_wa, nullptr, tid - 256);
-                }
-                prev = whi;
-                advance(in, cur);
-                __syncthreads();  // pixel stage and (hi) slab of chunk `step` are in place
-                ++step;
+        // ---- producer waves: never touch the accumulators (separate register budget).  They run one chunk ahead of the
+        // MFMA waves across tile boundaries, so a tile's first chunk streams in while the previous tile is still being
+        // multiplied and written out.
+        //
+        // A chunk = the haloed 18 x 34 pixel tile of 32 channels (612 pixels x 4 slots of 8 channels) + its weight slab(s).
+        // Pixels move in ROUNDS of G items per thread, software-pipelined two deep ACROSS chunk boundaries: while round r
+        // is modulated and written to LDS, round r + 1 -- for the last round of a chunk: round 0 of the NEXT chunk, and the
+        // next chunk's weight slabs -- is already in flight.  The loads land in registers, which nobody else sees, so they
+        // may be in flight across the workgroup barrier; the barrier here therefore waits for this wave's LDS traffic only
+        // (lds_barrier; __syncthreads() would drain vmcnt and expose one full HBM latency per chunk: measured 21.6k
+        // of a chunk's 25.5k cycles in the loader with the pipeline restarted per chunk).
+        // Split weights (w = hi + lo, both bf16; DESIGN.md 6, finding 15):
+        //   SPLIT = 0: slab hi -> slab buffer (step & 1), after the pixel rounds.
+        //   SPLIT = 1: (MT = 2: four slabs do not fit LDS) the consumers run every chunk twice, once per part, out of ONE
+        //              pixel stage; lds_wa holds hi parts, lds_wb lo parts.  The low part of the PREVIOUS chunk is written
+        //              first, then comes the barrier that separates the consumers' hi and lo half-steps of that chunk
+        //              (skipped for the very first chunk), then the rest of the pixels and the high part of this chunk.
+        //   SPLIT = 2: (MT = 1) both parts of THIS chunk go to [hi][lo] of slab pair (step & 1) after the pixel rounds; the
+        //              consumers issue two MFMAs per pixel fragment.
+        const int ltid = tid - 256;
+        constexpr int G = BANDS ? 2 : 5;
+        constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
+        constexpr int RA = ROUNDS / 2;  // rounds ahead of the mid barrier (SPLIT = 1)
+        constexpr int WITEMS = 9 * MT * 32 * 4;
+        constexpr int WG = (WITEMS + 255) / 256;
+        struct Batch {
+            uint4 vx[G], a2[G], a4[G], a8[G];
+            float4 gg[G];
+        };
+        struct Desc {  // one chunk of one tile
+            int b, h0, w0, o_blk, s, cc, kc;
+        };
+        const int Ws = W >> in.ups;
+        auto locate = [&](const Desc& d, int it, int& chunk, int& pi, int& h, int& w) {
+            if (in.x[d.s].ld == 8) {  // blocks of 8 channels: a block's pixels are contiguous, pixels fastest
+                chunk = it / NPIX;
+                pi = it - chunk * NPIX;
+            } else {  // NHWC / blocks of 32: the 4 slots of a pixel are contiguous
+                chunk = it & 3;
+                pi = it >> 2;
             }
-        }
-        if (SPLIT == 1) {  // low part of the very last chunk
-            constexpr int WITEMS = 9 * MT * 32 * 4;
-            const int ltid = tid - 256;
-            for (int it = ltid; it < WITEMS; it += 256) {
+            const int py = pi / PW, px = pi - py * PW;
+            h = d.h0 + py - 1;
+            w = d.w0 + px - 1;
+        };
+        auto issue = [&](const Desc& d, int r, Batch& bt) {
+            const View vx = in.x[d.s];
+            const bf16_t* xb = (const bf16_t*)vx.p + (long)d.b * vx.bs;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int chunk, pi, h, w;
+                locate(d, ltid + (r * G + g) * 256, chunk, pi, h, w);
+                // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards:
+                // a branch around a load makes hipcc drain the memory pipeline per element
+                const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+                const int ch = d.cc + (chunk & 3) * 8;
+                const unsigned ps = (unsigned)(hc >> in.ups) * Ws + (wc >> in.ups);
+                bt.vx[g] = *(const uint4*)(xb + voff32(vx, ps, ch));
+                if (BANDS) {
+                    const View v2 = in.l2[d.s], v4 = in.l4[d.s], v8 = in.l8[d.s];
+                    const unsigned p = (unsigned)hc * W + wc;
+                    bt.a2[g] = *(const uint4*)((const bf16_t*)v2.p + (long)d.b * v2.bs + voff32(v2, p, ch));
+                    bt.a4[g] = *(const uint4*)((const bf16_t*)v4.p + (long)d.b * v4.bs + voff32(v4, p, ch));
+                    bt.a8[g] = *(const uint4*)((const bf16_t*)v8.p + (long)d.b * v8.bs + voff32(v8, p, ch));
+                    bt.gg[g] = ((const float4*)gates)[(long)d.b * H * W + p];
+                }
+            }
+        };
+        auto consume = [&](const Desc& d, int r, const Batch& bt, char* lds_px) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int it = ltid + (r * G + g) * 256;
+                int chunk, pi, h, w;
+                locate(d, it, chunk, pi, h, w);
+                uint4 v = bt.vx[g];
+                if (BANDS) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
+                if (!(h >= 0 && h < H && w >= 0 && w < W)) v = make_uint4(0u, 0u, 0u, 0u);
+                if (it < NPIX * 4) *(uint4*)(lds_px + swz(pi, chunk)) = v;
+            }
+        };
+        // weight slab of chunk d: rows (tap, o) x 32 channels, L2-resident
+        auto wload = [&](const Desc& d, long part_off, uint4 (&wv)[WG]) {
+            const bf16_t* base = wts + (long)d.b * w_bstride + part_off;
+#pragma unroll
+            for (int g = 0; g < WG; ++g) {
+                const int it = ltid + g * 256;
                 const int chunk = it & 3, row = it >> 2;
                 const int tap = row / (MT * 32), o = row - tap * (MT * 32);
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (prev.o_blk + o < cout) v = *(const uint4*)(prev.base + w_lo_off + ((long)tap * cout + prev.o_blk + o) * cin + prev.kc + chunk * 8);
-                *(uint4*)(lds_wb + swz(row, chunk)) = v;
+                const int tapc = min(tap, 8), oc = min(d.o_blk + o, cout - 1);
+                wv[g] = *(const uint4*)(base + ((long)tapc * cout + oc) * cin + d.kc + chunk * 8);
+                if (d.o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
             }
-            __syncthreads();
+        };
+        auto wstore = [&](const uint4 (&wv)[WG], char* lds_w) {
+#pragma unroll
+            for (int g = 0; g < WG; ++g) {
+                const int it = ltid + g * 256;
+                if (it < WITEMS) *(uint4*)(lds_w + swz(it >> 2, it & 3)) = wv[g];
+            }
+        };
+        auto make_desc = [&](unsigned lin) {
+            const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
+            return Desc{t.b, t.h0, t.w0, t.o_blk, 0, 0, 0};
+        };
+        unsigned lin = walk.next;
+        Desc d = make_desc(lin);
+        Batch pre, oth;
+        uint4 wv_hi[WG], wv_lo[WG];
+        issue(d, 0, pre);
+        wload(d, 0, wv_hi);
+        if (SPLIT == 2) wload(d, w_lo_off, wv_lo);
+        unsigned step = 0;
+        unsigned long long dbg_t = DBG == 6 ? clock64() : 0;
+        bool more = true;
+        while (more) {
+            // the chunk after this one (this tile's next 32 channels, or the first chunk of the workgroup's next tile);
+            // past the end: this chunk again, as a valid address for loads nobody consumes
+            Desc dn = d;
+            dn.cc += 32;
+            dn.kc += 32;
+            if (dn.cc >= in.x[dn.s].C) {
+                dn.cc = 0;
+                dn.s += 1;
+            }
+            if (dn.s >= in.nseg) {
+                lin += walk.stride;
+                more = lin < walk.end;
+                dn = more ? make_desc(lin) : d;
+            }
+            char* px = lds + (step & 1) * STAGE_PX;
+            if (SPLIT == 1 && step) wstore(wv_lo, lds_wb);  // lo(previous chunk): the consumers are in its hi half-step
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                if (SPLIT == 1 && r == RA && step) lds_barrier();  // lo part of the previous chunk is in place
+                Batch& cur_b = (r & 1) ? oth : pre;
+                Batch& nxt_b = (r & 1) ? pre : oth;
+                if (r + 1 < ROUNDS) issue(d, r + 1, nxt_b);
+                else issue(dn, 0, nxt_b);
+                consume(d, r, cur_b, px);
+            }
+            if (ROUNDS & 1) pre = oth;  // the next chunk's round 0 sits in `oth` after an odd number of rounds
+            if (SPLIT == 0) wstore(wv_hi, (step & 1) ? lds_wb : lds_wa);
+            if (SPLIT == 1) wstore(wv_hi, lds_wa);
+            if (SPLIT == 2) {
+                char* slab = lds_wa + (step & 1) * 2 * WSLAB;
+                wstore(wv_hi, slab);
+                wstore(wv_lo, slab + WSLAB);
+            }
+            if (SPLIT == 1) wload(d, w_lo_off, wv_lo);  // stored at the start of the next chunk (or by the tail below)
+            wload(dn, 0, wv_hi);
+            if (SPLIT == 2) wload(dn, w_lo_off, wv_lo);
+            const unsigned long long tb = DBG == 6 ? clock64() : 0;
+            lds_barrier();  // pixel stage and (hi) slab of chunk `step` are in place
+            if (DBG == 6 && blockIdx.x == 0 && tid == 256) {
+                const unsigned long long tc = clock64();
+                atomicAdd(&g_dbg_cycles[5], tb - dbg_t);
+                atomicAdd(&g_dbg_cycles[6], tc - tb);
+                dbg_t = tc;
+            }
+            d = dn;
+            ++step;
+        }
+        if (SPLIT == 1) {  // low part of the very last chunk
+            wstore(wv_lo, lds_wb);
+            lds_barrier();
         }
         return;
     }
+    unsigned long long dbg_end = DBG == 6 ? clock64() : 0;
     unsigned step = 0;
     float* bias_lds = (float*)(lds + 2 * STAGE_PX + (SPLIT == 2 ? 4 : 2) * WSLAB);  // [cout], zeros without a bias
     float* slope_lds = bias_lds + cout;  // [cout] negative slopes: PReLU's, 0.2 for LeakyReLU, 1 without activation
@@ -436,42 +434,81 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-        auto multiply = [&](const char* cur_px, const char* cur_w, const char* cur_w2) {
-            // dy stays a real loop: fully unrolled, the 36 swizzled pixel addresses are hoisted into registers and
-            // (with 128 accumulators at MT = 2) spill; reloading spills inside this loop costs more than the few
-            // address instructions per iteration
-#pragma unroll 1
-            for (int dy = 0; dy < 3; ++dy)
+        // One k-step = (tap, half of the 32-channel chunk): MT weight fragments (x2 with fused split weights) and 4 pixel
+        // fragments feed 4*MT (x2) MFMAs.  The fragments of step s + 1 are requested BEFORE the MFMAs of step s are
+        // issued (two register sets): left to itself the compiler reads one pixel fragment, waits for it, issues the two
+        // MFMAs that use it and only then computes the next address -- every pair of MFMAs then pays a full LDS latency
+        // (measured: ~100 cycles per MFMA instead of 32; the second half-step of a split MT = 2 chunk cost +25 %).
+        struct Frags {
+            short8 a[MT], a2[MT], b[4];
+        };
+        auto load_step = [&](int dy, int dx, int kk, Frags& f, const char* cur_px, const char* cur_w, const char* cur_w2) {
+            const int tap = dy * 3 + dx;
+            const int chunk = kk * 2 + hk;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int tap = dy * 3 + dx;
+            for (int m = 0; m < MT; ++m) {
+                const int wo = swz(tap * (MT * 32) + m * 32 + r, chunk);
+                f.a[m] = *(const short8*)(cur_w + wo);
+                if (SPLIT == 2) f.a2[m] = *(const short8*)(cur_w2 + wo);
+            }
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int chunk = kk * 2 + hk;
-                    short8 af[MT], af2[MT];
+            for (int n = 0; n < 4; ++n) {
+                const int pi = (wave * 4 + n + dy) * PW + r + dx;
+                f.b[n] = *(const short8*)(cur_px + swz(pi, chunk));
+            }
+        };
+        auto mfma_step = [&](const Frags& f) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int wo = swz(tap * (MT * 32) + m * 32 + r, chunk);
-                        af[m] = *(const short8*)(cur_w + wo);
-                        if (SPLIT == 2) af2[m] = *(const short8*)(cur_w2 + wo);
-                    }
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const int pi = (wave * 4 + n + dy) * PW + r + dx;
-                        const short8 bf = *(const short8*)(cur_px + swz(pi, chunk));
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf, acc[m][n], 0, 0, 0);
-                            if (SPLIT == 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[m], bf, acc[m][n], 0, 0, 0);
-                        }
-                    }
+                for (int m = 0; m < MT; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
+                    if (SPLIT == 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a2[m], f.b[n], acc[m][n], 0, 0, 0);
                 }
+        };
+        auto multiply = [&](const char* cur_px, const char* cur_w, const char* cur_w2) {
+            Frags f0, f1;
+            load_step(0, 0, 0, f0, cur_px, cur_w, cur_w2);
+            // dy stays a real loop: fully unrolled, the 36 swizzled pixel addresses are hoisted into registers and
+            // (with 128 accumulators at MT = 2) spill
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                load_step(dy, 0, 1, f1, cur_px, cur_w, cur_w2);
+                mfma_step(f0);
+                load_step(dy, 1, 0, f0, cur_px, cur_w, cur_w2);
+                mfma_step(f1);
+                load_step(dy, 1, 1, f1, cur_px, cur_w, cur_w2);
+                mfma_step(f0);
+                load_step(dy, 2, 0, f0, cur_px, cur_w, cur_w2);
+                mfma_step(f1);
+                load_step(dy, 2, 1, f1, cur_px, cur_w, cur_w2);
+                mfma_step(f0);
+                load_step(dy < 2 ? dy + 1 : 2, 0, 0, f0, cur_px, cur_w, cur_w2);  // last round: a harmless re-read, no branch
+                mfma_step(f1);
             }
         };
         for (int c = 0; c < nchunks; ++c) {
             const char* cur_px = lds + (step & 1) * STAGE_PX;
+            const unsigned long long t0 = DBG == 6 ? clock64() : 0;
             __syncthreads();  // chunk `step`: pixel stage and (hi) slab are in place; the previous chunk is consumed
-            if (SPLIT == 1) {
+            if (DBG == 6) {
+                const unsigned long long t1 = clock64();
+                multiply(cur_px, lds_wa, nullptr);
+                const unsigned long long t2 = clock64();
+                lds_barrier();
+                const unsigned long long t3 = clock64();
+                multiply(cur_px, lds_wb, nullptr);
+                const unsigned long long t4 = clock64();
+                if (blockIdx.x == 0 && tid == 0) {
+                    atomicAdd(&g_dbg_cycles[0], t1 - t0);
+                    atomicAdd(&g_dbg_cycles[1], t2 - t1);
+                    atomicAdd(&g_dbg_cycles[2], t3 - t2);
+                    atomicAdd(&g_dbg_cycles[3], t4 - t3);
+                    atomicAdd(&g_dbg_cycles[4], t0 - dbg_end);
+                    atomicAdd(&g_dbg_cycles[7], 1ull);
+                }
+                dbg_end = t4;
+            } else if (SPLIT == 1) {
                 multiply(cur_px, lds_wa, nullptr);
                 lds_barrier();  // lo slab of this chunk is in place
                 multiply(cur_px, lds_wb, nullptr);
@@ -515,12 +552,17 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                     continue;
                 }
                 // bias (staged in LDS once per workgroup) + activation, written back over the accumulators
-                const float* bl = bias_lds + o_blk + m * 32 + hk * 16;
-                const float* sl = slope_lds + o_blk + m * 32 + hk * 16;
+                const float4* bl = (const float4*)(bias_lds + o_blk + m * 32 + hk * 16);  // 16-byte aligned: four reads, not 16
+                const float4* sl = (const float4*)(slope_lds + o_blk + m * 32 + hk * 16);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float v = y[j] + bl[j];
-                    acc[m][n][j] = v > 0.f ? v : sl[j] * v;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = bl[q], ss = sl[q];
+                    const float bq[4] = {bb.x, bb.y, bb.z, bb.w}, sq[4] = {ss.x, ss.y, ss.z, ss.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = y[4 * q + j] + bq[j];
+                        acc[m][n][4 * q + j] = v > 0.f ? v : sq[j] * v;
+                    }
                 }
             }
         }
@@ -597,23 +639,24 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
     return true;
 }
 
-template <int MT, bool BANDS, int SPLIT>
+template <int MT, bool BANDS, int SPLIT, int DBG = 0>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
     const size_t ldsb = 2 * (size_t)NPIX * 64 + (SPLIT == 2 ? 4 : 2) * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
-    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT>);  // per device
+    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT, DBG>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
     if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-    conv3x3_mfma_bf16<MT, BANDS, SPLIT><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk);
+    conv3x3_mfma_bf16<MT, BANDS, SPLIT, DBG><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
 
 int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
+int g_conv_dbg = 0;  // 6: the cycle-counting instance of the split MT = 2 kernel (tools/bench_ops.py conv_ab)
 int g_split_two_pass = 0;  // A/B hook: two half-steps per chunk also where the fused form fits (MT = 1)
 
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
@@ -624,6 +667,7 @@ int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float
         if (wlo % 8 != 0) return SR_ERR_ARG;
 #define SR_MFMA(MT, BANDS, SPLIT) launch_mfma<MT, BANDS, SPLIT>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
         if (in.bands) {
+            if (wlo && two && g_conv_dbg == 6) return launch_mfma<2, true, 1, 6>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
             if (wlo) return two ? SR_MFMA(2, true, 1) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
             return two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
         }
@@ -660,3 +704,10 @@ extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, c
 extern "C" void sr_debug_force_generic_conv(int on) { sr::g_force_generic = on; }
 
 extern "C" void sr_debug_split_two_pass(int on) { sr::g_split_two_pass = on; }
+extern "C" void sr_debug_conv_variant(int v) { sr::g_conv_dbg = v; }
+// timing experiment: read (and clear) the cycle counters of the DBG == 6 kernel
+extern "C" int sr_debug_conv_cycles(unsigned long long* out8) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sr::g_dbg_cycles), sizeof(z)) != hipSuccess) return -3;
+    return hipMemcpyToSymbol(HIP_SYMBOL(sr::g_dbg_cycles), z, sizeof(z)) == hipSuccess ? 0 : -3;
+}

@@ -62,14 +62,14 @@ def lowpass(Cc=32, H=512, W=512, B=16, reps=10, blocked=0, force_fft=1, ups=0):
           (Cc, H, W, B, blocked, force_fft, ups, t * 1e6, 8.0, px * 8 / t / 1e12))
 
 
-def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
+def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0, split=0, variant=0):
     segs = [64] + [32] * ((cin - 64) // 32)
     shp = (lambda c: (B, c // blocked, H, W, blocked)) if blocked else (lambda c: (B, H, W, c))
     mk = L.blocked_view if blocked else L.view
     xs = [torch.rand(shp(c), device=dev).to(torch.bfloat16) for c in segs]
     bs = [[torch.rand(shp(c), device=dev).to(torch.bfloat16) for _ in range(3)] for c in segs]
     gates = torch.rand(B, H, W, 4, device=dev) * 2
-    wd = (torch.randn(B, 9, cout, cin, device=dev) * 0.05).to(torch.bfloat16)
+    wd = (torch.randn(2, B, 9, cout, cin, device=dev) * 0.05).to(torch.bfloat16)
     out = torch.empty(shp(cout), device=dev, dtype=torch.bfloat16)
     cc = L.Concat()
     cc.nseg, cc.bands = len(segs), bands
@@ -80,13 +80,23 @@ def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0):
     ep.lrelu = 1
 
     def run():
-        L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin, 0, cout, C.byref(ep),
-                               mk(out), st))
+        L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin,
+                               B * 9 * cout * cin if split else 0, cout, C.byref(ep), mk(out), st))
+    lib.sr_debug_conv_variant(variant)
+    cyc = (C.c_ulonglong * 8)()
+    lib.sr_debug_conv_cycles(cyc)
     t = timeit(run, reps)
+    lib.sr_debug_conv_variant(0)
+    if variant == 6:
+        torch.cuda.synchronize()
+        lib.sr_debug_conv_cycles(cyc)
+        n = max(cyc[7], 1)
+        print('  per chunk (cycles, 100 MHz-independent s_memtime ticks): consumer wait %.0f  hi %.0f  mid wait %.0f  lo %.0f  epilogue/tile-setup %.0f | '
+              'loader stage %.0f  loader wait %.0f  (%d chunks)' % tuple([cyc[i] / n for i in range(7)] + [n]))
     px = B * H * W
     byts = px * ((4 if bands else 1) * cin * 2 + (16 if bands else 0) + cout * 2)
-    print('conv %d->%d %dx%d B=%d bands=%d blocked=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic' %
-          (cin, cout, H, W, B, bands, blocked, t * 1e6, 2.0 * 9 * cin * cout * px / t / 1e12, byts / t / 1e12))
+    print('conv %d->%d %dx%d B=%d bands=%d blocked=%d split=%d variant=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic' %
+          (cin, cout, H, W, B, bands, blocked, split, variant, t * 1e6, 2.0 * 9 * cin * cout * px / t / 1e12, byts / t / 1e12))
 
 
 def gates(cin=160, H=512, W=512, B=16, reps=10, blocked=0):
@@ -132,4 +142,7 @@ def all_ops():
 if __name__ == '__main__':
     op = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {'lowpass': lowpass, 'conv': conv, 'gates': gates, 'all': all_ops}[op](*args)
+    def conv_ab():
+        for split, variant in ((0, 0), (1, 0), (1, 6), (1, 6)):
+            conv(192, 64, 512, 512, 16, 10, 1, 32, split, variant)
+    {'lowpass': lowpass, 'conv': conv, 'gates': gates, 'all': all_ops, 'conv_ab': conv_ab}[op](*args)
