@@ -146,16 +146,30 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// g1*x + (g2-g1)*L2 + (g3-g2)*L4 + (1-g3)*L8 on 8 bf16 channels: channel pairs as float2, one v_pk_mul_f32 + three
+// v_pk_fma_f32 per pair (written as four products and three adds the compiler used ten instructions per pair)
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v unpack2(uint32_t u) {
+    float2v r;
+    r.x = lo_f(u);
+    r.y = hi_f(u);
+    return r;
+}
+__device__ __forceinline__ uint32_t modulate2(uint32_t x, uint32_t a, uint32_t b, uint32_t c, float2v c0, float2v c1, float2v c2,
+                                              float2v c3) {
+    float2v r = c0 * unpack2(x);
+    r = __builtin_elementwise_fma(c1, unpack2(a), r);
+    r = __builtin_elementwise_fma(c2, unpack2(b), r);
+    r = __builtin_elementwise_fma(c3, unpack2(c), r);
+    return pack2(r.x, r.y);
+}
 __device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, float c0, float c1, float c2, float c3) {
+    const float2v k0 = {c0, c0}, k1 = {c1, c1}, k2 = {c2, c2}, k3 = {c3, c3};
     uint4 r;
-    r.x = pack2(c0 * lo_f(x.x) + c1 * lo_f(a.x) + c2 * lo_f(b.x) + c3 * lo_f(c.x),
-                c0 * hi_f(x.x) + c1 * hi_f(a.x) + c2 * hi_f(b.x) + c3 * hi_f(c.x));
-    r.y = pack2(c0 * lo_f(x.y) + c1 * lo_f(a.y) + c2 * lo_f(b.y) + c3 * lo_f(c.y),
-                c0 * hi_f(x.y) + c1 * hi_f(a.y) + c2 * hi_f(b.y) + c3 * hi_f(c.y));
-    r.z = pack2(c0 * lo_f(x.z) + c1 * lo_f(a.z) + c2 * lo_f(b.z) + c3 * lo_f(c.z),
-                c0 * hi_f(x.z) + c1 * hi_f(a.z) + c2 * hi_f(b.z) + c3 * hi_f(c.z));
-    r.w = pack2(c0 * lo_f(x.w) + c1 * lo_f(a.w) + c2 * lo_f(b.w) + c3 * lo_f(c.w),
-                c0 * hi_f(x.w) + c1 * hi_f(a.w) + c2 * hi_f(b.w) + c3 * hi_f(c.w));
+    r.x = modulate2(x.x, a.x, b.x, c.x, k0, k1, k2, k3);
+    r.y = modulate2(x.y, a.y, b.y, c.y, k0, k1, k2, k3);
+    r.z = modulate2(x.z, a.z, b.z, c.z, k0, k1, k2, k3);
+    r.w = modulate2(x.w, a.w, b.w, c.w, k0, k1, k2, k3);
     return r;
 }
 
@@ -224,6 +238,7 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
 // SPLIT != 0: wts holds the high parts, wts + w_lo_off the low parts of the same [B][9][cout][cin] weights.
 // Barrier protocol (every wave executes the same number of workgroup barriers):
 //   SPLIT 0, 2: loaders  fill(chunk s) -> barrier_s          consumers  barrier_s -> multiply(chunk s)
+//   SPLIT 3   : loaders  pixels(s) -> barrier_{2s} -> hi(s), lo(s) -> barrier_{2s+1}    consumers  barrier_{2s} -> barrier_{2s+1} -> multiply(s)
 //   SPLIT 1   : loaders  [lo(s-1), pixels A] -> barrier_{2s-1} -> [pixels B, hi(s)] -> barrier_{2s}; after the last chunk
 //               lo(last) -> barrier;          consumers  barrier_{2s} -> hi(s) -> barrier_{2s+1} -> lo(s)
 // LDS: two pixel stages, then the slabs: SPLIT 0: [stage 0][stage 1]; SPLIT 1: [hi][lo]; SPLIT 2: [s0 hi][s0 lo][s1 hi][s1 lo].
@@ -267,6 +282,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         //              (skipped for the very first chunk), then the rest of the pixels and the high part of this chunk.
         //   SPLIT = 2: (MT = 1) both parts of THIS chunk go to [hi][lo] of slab pair (step & 1) after the pixel rounds; the
         //              consumers issue two MFMAs per pixel fragment.
+        //   SPLIT = 3: (MT = 2) the same fused form with ONE slab pair: the loaders wait for the consumers to finish the
+        //              previous chunk, write both slabs from registers and release them with a second barrier.  The
+        //              consumers read every pixel fragment once (SPLIT = 1 reads it twice and cannot run ahead of the
+        //              mid barrier); their wait for the slab write is short next to the loaders' pixel stream.
         const int ltid = tid - 256;
         constexpr int G = BANDS ? 2 : 5;
         constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
@@ -281,51 +300,96 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             int b, h0, w0, o_blk, s, cc, kc;
         };
         const int Ws = W >> in.ups;
-        auto locate = [&](const Desc& d, int it, int& chunk, int& pi, int& h, int& w) {
-            if (in.x[d.s].ld == 8) {  // blocks of 8 channels: a block's pixels are contiguous, pixels fastest
-                chunk = it / NPIX;
-                pi = it - chunk * NPIX;
-            } else {  // NHWC / blocks of 32: the 4 slots of a pixel are contiguous
-                chunk = it & 3;
+        // Addressing is split by how often it changes (the loaders' own instruction issue was a measured third of a
+        // chunk's time; divisions and 64-bit address arithmetic per item and chunk made up half of it):
+        //   per kernel  item k of this thread -> 8-channel slot and LDS offset inside the haloed tile
+        //               (two layouts: slots of a pixel adjacent, or -- blocks of 8 channels -- pixels of a slot adjacent);
+        //   per tile    clamped image row / column of the items and the inside-image bits;
+        //   per chunk   one uniform base pointer per tensor and, per thread, the element offset of its slot's channels;
+        //   per item    byte offset = pixel offset * pixel stride + slot offset: one v_mad per tensor, added to the
+        //               uniform base by the load itself.
+        constexpr int NIT = ROUNDS * G;
+        unsigned it_lds[NIT];  // swz(pi, slot) | slot << 16
+        unsigned it_hw[NIT];   // clamped (row << 16 | column) of the item in the current tile
+        unsigned inside = 0;   // bit k: item k lies inside the image
+        int geo_kind = -1;
+        auto item_pos = [&](int kind, int k, int& slot, int& pi) {
+            const int it = ltid + k * 256;
+            if (kind) {
+                slot = it / NPIX;
+                pi = it - slot * NPIX;
+            } else {
+                slot = it & 3;
                 pi = it >> 2;
             }
-            const int py = pi / PW, px = pi - py * PW;
-            h = d.h0 + py - 1;
-            w = d.w0 + px - 1;
+            slot &= 3;
         };
+        auto build_geo = [&](int kind) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                int slot, pi;
+                item_pos(kind, k, slot, pi);
+                it_lds[k] = (unsigned)swz(pi, slot) | ((unsigned)slot << 16);
+            }
+            geo_kind = kind;
+        };
+        auto build_tile = [&](const Desc& d) {
+            inside = 0;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                int slot, pi;
+                item_pos(geo_kind, k, slot, pi);
+                const int py = pi / PW, px = pi - py * PW;
+                const int h = d.h0 + py - 1, w = d.w0 + px - 1;
+                const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+                it_hw[k] = ((unsigned)hc << 16) | (unsigned)wc;
+                if (h == hc && w == wc) inside |= 1u << k;
+            }
+        };
+        // element offset of the thread's 8-channel slot `q` of chunk d inside view v (sample and pixel terms excluded)
+        auto slot_off = [&](const View& v, const Desc& d, unsigned q) {
+            const unsigned cc = (unsigned)(v.c0 + d.cc) + 8u * q;
+            return (cc >> v.csh) * (unsigned)v.cbs + (cc & ((1u << v.csh) - 1u));
+        };
+        // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards: a branch around
+        // a load makes hipcc drain the memory pipeline per element
         auto issue = [&](const Desc& d, int r, Batch& bt) {
             const View vx = in.x[d.s];
-            const bf16_t* xb = (const bf16_t*)vx.p + (long)d.b * vx.bs;
+            const char* xb = (const char*)((const bf16_t*)vx.p + (long)d.b * vx.bs);
+            const View v2 = in.l2[d.s], v4 = in.l4[d.s], v8 = in.l8[d.s];
+            const char* b2 = BANDS ? (const char*)((const bf16_t*)v2.p + (long)d.b * v2.bs) : nullptr;
+            const char* b4 = BANDS ? (const char*)((const bf16_t*)v4.p + (long)d.b * v4.bs) : nullptr;
+            const char* b8 = BANDS ? (const char*)((const bf16_t*)v8.p + (long)d.b * v8.bs) : nullptr;
+            const char* gb = (const char*)((const float4*)gates + (long)d.b * H * W);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                int chunk, pi, h, w;
-                locate(d, ltid + (r * G + g) * 256, chunk, pi, h, w);
-                // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards:
-                // a branch around a load makes hipcc drain the memory pipeline per element
-                const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
-                const int ch = d.cc + (chunk & 3) * 8;
-                const unsigned ps = (unsigned)(hc >> in.ups) * Ws + (wc >> in.ups);
-                bt.vx[g] = *(const uint4*)(xb + voff32(vx, ps, ch));
+                const int k = r * G + g;
+                const unsigned q = it_lds[k] >> 16;
+                const unsigned hc = it_hw[k] >> 16, wc = it_hw[k] & 0xffffu;
+                const unsigned p = hc * (unsigned)W + wc;
+                const unsigned ps = in.ups ? (hc >> 1) * (unsigned)Ws + (wc >> 1) : p;
+                bt.vx[g] = *(const uint4*)(xb + (size_t)(2u * (ps * (unsigned)vx.ld + slot_off(vx, d, q))));
                 if (BANDS) {
-                    const View v2 = in.l2[d.s], v4 = in.l4[d.s], v8 = in.l8[d.s];
-                    const unsigned p = (unsigned)hc * W + wc;
-                    bt.a2[g] = *(const uint4*)((const bf16_t*)v2.p + (long)d.b * v2.bs + voff32(v2, p, ch));
-                    bt.a4[g] = *(const uint4*)((const bf16_t*)v4.p + (long)d.b * v4.bs + voff32(v4, p, ch));
-                    bt.a8[g] = *(const uint4*)((const bf16_t*)v8.p + (long)d.b * v8.bs + voff32(v8, p, ch));
-                    bt.gg[g] = ((const float4*)gates)[(long)d.b * H * W + p];
+                    if (DBG != 15) {
+                        bt.a2[g] = *(const uint4*)(b2 + (size_t)(2u * (p * (unsigned)v2.ld + slot_off(v2, d, q))));
+                        bt.a4[g] = *(const uint4*)(b4 + (size_t)(2u * (p * (unsigned)v4.ld + slot_off(v4, d, q))));
+                        bt.a8[g] = *(const uint4*)(b8 + (size_t)(2u * (p * (unsigned)v8.ld + slot_off(v8, d, q))));
+                    } else {
+                        bt.a2[g] = bt.a4[g] = bt.a8[g] = bt.vx[g];
+                    }
+                    if (DBG != 11) bt.gg[g] = *(const float4*)(gb + (size_t)(p << 4));
+                    else bt.gg[g] = make_float4(1.f, 0.5f, 0.25f, 0.f);
                 }
             }
         };
-        auto consume = [&](const Desc& d, int r, const Batch& bt, char* lds_px) {
+        auto consume = [&](int r, const Batch& bt, char* lds_px) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int it = ltid + (r * G + g) * 256;
-                int chunk, pi, h, w;
-                locate(d, it, chunk, pi, h, w);
+                const int k = r * G + g;
                 uint4 v = bt.vx[g];
-                if (BANDS) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
-                if (!(h >= 0 && h < H && w >= 0 && w < W)) v = make_uint4(0u, 0u, 0u, 0u);
-                if (it < NPIX * 4) *(uint4*)(lds_px + swz(pi, chunk)) = v;
+                if (BANDS && DBG != 13) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
+                if (!((inside >> k) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if ((k + 1) * 256 <= NPIX * 4 || ltid + k * 256 < NPIX * 4) *(uint4*)(lds_px + (it_lds[k] & 0xffffu)) = v;
             }
         };
         // weight slab of chunk d: rows (tap, o) x 32 channels, L2-resident
@@ -337,7 +401,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 const int chunk = it & 3, row = it >> 2;
                 const int tap = row / (MT * 32), o = row - tap * (MT * 32);
                 const int tapc = min(tap, 8), oc = min(d.o_blk + o, cout - 1);
-                wv[g] = *(const uint4*)(base + ((long)tapc * cout + oc) * cin + d.kc + chunk * 8);
+                if (DBG != 12) wv[g] = *(const uint4*)(base + ((long)tapc * cout + oc) * cin + d.kc + chunk * 8);
+                else wv[g] = make_uint4(it, it, it, it);
                 if (d.o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
             }
         };
@@ -356,9 +421,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         Desc d = make_desc(lin);
         Batch pre, oth;
         uint4 wv_hi[WG], wv_lo[WG];
+        build_geo(in.x[0].ld == 8);
+        build_tile(d);
         issue(d, 0, pre);
         wload(d, 0, wv_hi);
-        if (SPLIT == 2) wload(d, w_lo_off, wv_lo);
+        if (SPLIT >= 2) wload(d, w_lo_off, wv_lo);
         unsigned step = 0;
         unsigned long long dbg_t = DBG == 6 ? clock64() : 0;
         bool more = true;
@@ -384,9 +451,27 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 if (SPLIT == 1 && r == RA && step) lds_barrier();  // lo part of the previous chunk is in place
                 Batch& cur_b = (r & 1) ? oth : pre;
                 Batch& nxt_b = (r & 1) ? pre : oth;
-                if (r + 1 < ROUNDS) issue(d, r + 1, nxt_b);
-                else issue(dn, 0, nxt_b);
-                consume(d, r, cur_b, px);
+                if (r + 1 < ROUNDS) {
+                    issue(d, r + 1, nxt_b);
+                    consume(r, cur_b, px);
+                } else {
+                    // last round: this chunk's loads are all in registers; retarget the tables, then start the next chunk
+                    const int kind_n = in.x[dn.s].ld == 8;
+                    if (kind_n != geo_kind) {  // segments of different layouts in one concat (rare): no overlap here
+                        consume(r, cur_b, px);
+                        build_geo(kind_n);
+                        build_tile(dn);
+                        issue(dn, 0, nxt_b);
+                    } else {
+                        const unsigned inside_d = inside;
+                        if (dn.b != d.b || dn.h0 != d.h0 || dn.w0 != d.w0) build_tile(dn);
+                        issue(dn, 0, nxt_b);
+                        const unsigned inside_n = inside;
+                        inside = inside_d;
+                        consume(r, cur_b, px);
+                        inside = inside_n;
+                    }
+                }
             }
             if (ROUNDS & 1) pre = oth;  // the next chunk's round 0 sits in `oth` after an odd number of rounds
             if (SPLIT == 0) wstore(wv_hi, (step & 1) ? lds_wb : lds_wa);
@@ -396,9 +481,14 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 wstore(wv_hi, slab);
                 wstore(wv_lo, slab + WSLAB);
             }
+            if (SPLIT == 3) {
+                lds_barrier();  // the consumers have finished the previous chunk: the single slab pair is free
+                wstore(wv_hi, lds_wa);
+                wstore(wv_lo, lds_wb);
+            }
             if (SPLIT == 1) wload(d, w_lo_off, wv_lo);  // stored at the start of the next chunk (or by the tail below)
             wload(dn, 0, wv_hi);
-            if (SPLIT == 2) wload(dn, w_lo_off, wv_lo);
+            if (SPLIT >= 2) wload(dn, w_lo_off, wv_lo);
             const unsigned long long tb = DBG == 6 ? clock64() : 0;
             lds_barrier();  // pixel stage and (hi) slab of chunk `step` are in place
             if (DBG == 6 && blockIdx.x == 0 && tid == 256) {
@@ -449,7 +539,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int m = 0; m < MT; ++m) {
                 const int wo = swz(tap * (MT * 32) + m * 32 + r, chunk);
                 f.a[m] = *(const short8*)(cur_w + wo);
-                if (SPLIT == 2) f.a2[m] = *(const short8*)(cur_w2 + wo);
+                if (SPLIT >= 2) f.a2[m] = *(const short8*)(cur_w2 + wo);
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -463,7 +553,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
-                    if (SPLIT == 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a2[m], f.b[n], acc[m][n], 0, 0, 0);
+                    if (SPLIT >= 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a2[m], f.b[n], acc[m][n], 0, 0, 0);
                 }
         };
         auto multiply = [&](const char* cur_px, const char* cur_w, const char* cur_w2) {
@@ -515,6 +605,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             } else if (SPLIT == 2) {
                 const char* slab = lds_wa + (step & 1) * 2 * WSLAB;
                 multiply(cur_px, slab, slab + WSLAB);
+            } else if (SPLIT == 3) {
+                lds_barrier();  // both slabs of this chunk are in place (the barrier above released them to the loaders)
+                multiply(cur_px, lds_wa, lds_wb);
             } else {
                 multiply(cur_px, (step & 1) ? lds_wb : lds_wa, nullptr);
             }
@@ -668,7 +761,10 @@ int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float
 #define SR_MFMA(MT, BANDS, SPLIT) launch_mfma<MT, BANDS, SPLIT>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
         if (in.bands) {
             if (wlo && two && g_conv_dbg == 6) return launch_mfma<2, true, 1, 6>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
-            if (wlo) return two ? SR_MFMA(2, true, 1) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
+#define SR_DBGV(V) if (wlo && g_conv_dbg == V) return two ? launch_mfma<2, true, 1, V>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st) : launch_mfma<1, true, 2, V>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
+            SR_DBGV(11) SR_DBGV(12) SR_DBGV(13) SR_DBGV(14) SR_DBGV(15)
+#undef SR_DBGV
+            if (wlo) return two ? (g_split_two_pass == 3 ? SR_MFMA(2, true, 3) : SR_MFMA(2, true, 1)) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
             return two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
         }
         if (wlo) return two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);

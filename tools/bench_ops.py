@@ -143,6 +143,7 @@ if __name__ == '__main__':
     op = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
     def conv_ab():
-        for split, variant in ((0, 0), (1, 0), (1, 6), (1, 6)):
-            conv(192, 64, 512, 512, 16, 10, 1, 32, split, variant)
+        for cin, cout in ((192, 64), (160, 32), (64, 32)):
+            for split in (1, 0, 1):
+                conv(cin, cout, 512, 512, 16, 10, 1, 32, split, 0)
     {'lowpass': lowpass, 'conv': conv, 'gates': gates, 'all': all_ops, 'conv_ab': conv_ab}[op](*args)
