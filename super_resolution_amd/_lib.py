@@ -106,8 +106,6 @@ _SIGS = {
     'sr_debug_force_generic_gates': (None, [C.c_int]),
     'sr_debug_split_weights': (None, [C.c_int]),
     'sr_debug_split_two_pass': (None, [C.c_int]),
-    'sr_debug_conv_variant': (None, [C.c_int]),
-    'sr_debug_conv_cycles': (C.c_int, [C.c_void_p]),
 }
 
 # every symbol include/sr_amd.h declares (the debug hook is not part of the header)

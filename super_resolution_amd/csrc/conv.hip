@@ -181,14 +181,14 @@ __device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, f
 //   waves 0-3 (MFMA)     run the 9 taps x 2 k-steps of the current chunk out of the other stage.
 // One barrier per chunk; the chunk time is max(HBM stream, MFMA), i.e. the kernel runs at whichever
 // roofline the layer is on (the banded FDConv operand is 4 tensors wide -> HBM).
-// timing experiment (DBG == 6): cycles of workgroup 0's first consumer / first loader wave
-//   0 consumer wait at the chunk barrier, 1 hi multiply, 2 wait at the mid barrier, 3 lo multiply, 4 epilogue (+ tile setup)
-//   5 loader stage_chunk, 6 loader wait at the chunk barrier, 7 chunks
-__device__ unsigned long long g_dbg_cycles[8];
-
 struct ChunkCursor {  // walks the virtual concat in 32-channel chunks
     int s, cc, kc;
 };
+
+// 16 bytes per lane global -> LDS without a register stop: LDS destination = wave-uniform `l` + lane * 16
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
 
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the wave's global loads
 // (s_waitcnt vmcnt(0)): at the barrier in the middle of a chunk that would empty the loaders' two-deep load pipeline
@@ -235,14 +235,15 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
     return t;
 }
 
-// SPLIT != 0: wts holds the high parts, wts + w_lo_off the low parts of the same [B][9][cout][cin] weights.
-// Barrier protocol (every wave executes the same number of workgroup barriers):
-//   SPLIT 0, 2: loaders  fill(chunk s) -> barrier_s          consumers  barrier_s -> multiply(chunk s)
-//   SPLIT 3   : loaders  pixels(s) -> barrier_{2s} -> hi(s), lo(s) -> barrier_{2s+1}    consumers  barrier_{2s} -> barrier_{2s+1} -> multiply(s)
-//   SPLIT 1   : loaders  [lo(s-1), pixels A] -> barrier_{2s-1} -> [pixels B, hi(s)] -> barrier_{2s}; after the last chunk
-//               lo(last) -> barrier;          consumers  barrier_{2s} -> hi(s) -> barrier_{2s+1} -> lo(s)
-// LDS: two pixel stages, then the slabs: SPLIT 0: [stage 0][stage 1]; SPLIT 1: [hi][lo]; SPLIT 2: [s0 hi][s0 lo][s1 hi][s1 lo].
-template <int MT, bool BANDS, int SPLIT, int DBG = 0>
+// SPLIT != 0: wts holds the high parts, wts + w_lo_off the low parts of the same [B][9][cout][cin] weights (w = hi + lo, both
+// bf16: the rounding of the dynamic weights, an error coherent over the whole image, was the dominant bf16 error of a deep
+// network -- DESIGN.md 6, finding 15); the MFMA waves then issue two MFMAs per pixel fragment, one per part.
+// LDS: two pixel stages, then the slabs:  SPLIT 0: hi of chunk parity 0 / 1;  SPLIT 2 (MT = 1): [hi][lo] per chunk parity;
+// SPLIT 1 (MT = 2): one [hi][lo] pair.  Barrier protocol (every wave executes the same number of workgroup barriers):
+//   SPLIT 0, 2: loaders  pixels(s) -> barrier_s                          MFMA waves  barrier_s -> DMA slabs(s+1) -> multiply(s)
+//   SPLIT 1   : loaders  pixels(s) first half -> barrier'_{s-1} -> second half -> barrier_s  (+ one barrier after the last chunk)
+//               MFMA waves  barrier_s -> multiply(s) -> barrier'_s -> DMA slabs(s+1)
+template <int MT, bool BANDS, int SPLIT>
 __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, long w_lo_off,
                                                          int cin, int cout, Epilogue ep, View out, unsigned total) {
@@ -274,24 +275,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         // may be in flight across the workgroup barrier; the barrier here therefore waits for this wave's LDS traffic only
         // (lds_barrier; __syncthreads() would drain vmcnt and expose one full HBM latency per chunk: measured 21.6k
         // of a chunk's 25.5k cycles in the loader with the pipeline restarted per chunk).
-        // Split weights (w = hi + lo, both bf16; DESIGN.md 6, finding 15):
-        //   SPLIT = 0: slab hi -> slab buffer (step & 1), after the pixel rounds.
-        //   SPLIT = 1: (MT = 2: four slabs do not fit LDS) the consumers run every chunk twice, once per part, out of ONE
-        //              pixel stage; lds_wa holds hi parts, lds_wb lo parts.  The low part of the PREVIOUS chunk is written
-        //              first, then comes the barrier that separates the consumers' hi and lo half-steps of that chunk
-        //              (skipped for the very first chunk), then the rest of the pixels and the high part of this chunk.
-        //   SPLIT = 2: (MT = 1) both parts of THIS chunk go to [hi][lo] of slab pair (step & 1) after the pixel rounds; the
-        //              consumers issue two MFMAs per pixel fragment.
-        //   SPLIT = 3: (MT = 2) the same fused form with ONE slab pair: the loaders wait for the consumers to finish the
-        //              previous chunk, write both slabs from registers and release them with a second barrier.  The
-        //              consumers read every pixel fragment once (SPLIT = 1 reads it twice and cannot run ahead of the
-        //              mid barrier); their wait for the slab write is short next to the loaders' pixel stream.
+        // The loaders move pixels only; the weight slabs are fetched by the MFMA waves themselves (LDS-DMA, below).
         const int ltid = tid - 256;
         constexpr int G = BANDS ? 2 : 5;
         constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
         constexpr int RA = ROUNDS / 2;  // rounds ahead of the mid barrier (SPLIT = 1)
-        constexpr int WITEMS = 9 * MT * 32 * 4;
-        constexpr int WG = (WITEMS + 255) / 256;
         struct Batch {
             uint4 vx[G], a2[G], a4[G], a8[G];
             float4 gg[G];
@@ -370,15 +358,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 const unsigned ps = in.ups ? (hc >> 1) * (unsigned)Ws + (wc >> 1) : p;
                 bt.vx[g] = *(const uint4*)(xb + (size_t)(2u * (ps * (unsigned)vx.ld + slot_off(vx, d, q))));
                 if (BANDS) {
-                    if (DBG != 15) {
-                        bt.a2[g] = *(const uint4*)(b2 + (size_t)(2u * (p * (unsigned)v2.ld + slot_off(v2, d, q))));
-                        bt.a4[g] = *(const uint4*)(b4 + (size_t)(2u * (p * (unsigned)v4.ld + slot_off(v4, d, q))));
-                        bt.a8[g] = *(const uint4*)(b8 + (size_t)(2u * (p * (unsigned)v8.ld + slot_off(v8, d, q))));
-                    } else {
-                        bt.a2[g] = bt.a4[g] = bt.a8[g] = bt.vx[g];
-                    }
-                    if (DBG != 11) bt.gg[g] = *(const float4*)(gb + (size_t)(p << 4));
-                    else bt.gg[g] = make_float4(1.f, 0.5f, 0.25f, 0.f);
+                    bt.a2[g] = *(const uint4*)(b2 + (size_t)(2u * (p * (unsigned)v2.ld + slot_off(v2, d, q))));
+                    bt.a4[g] = *(const uint4*)(b4 + (size_t)(2u * (p * (unsigned)v4.ld + slot_off(v4, d, q))));
+                    bt.a8[g] = *(const uint4*)(b8 + (size_t)(2u * (p * (unsigned)v8.ld + slot_off(v8, d, q))));
+                    bt.gg[g] = *(const float4*)(gb + (size_t)(p << 4));
                 }
             }
         };
@@ -387,30 +370,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int g = 0; g < G; ++g) {
                 const int k = r * G + g;
                 uint4 v = bt.vx[g];
-                if (BANDS && DBG != 13) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
+                if (BANDS) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
                 if (!((inside >> k) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                 if ((k + 1) * 256 <= NPIX * 4 || ltid + k * 256 < NPIX * 4) *(uint4*)(lds_px + (it_lds[k] & 0xffffu)) = v;
-            }
-        };
-        // weight slab of chunk d: rows (tap, o) x 32 channels, L2-resident
-        auto wload = [&](const Desc& d, long part_off, uint4 (&wv)[WG]) {
-            const bf16_t* base = wts + (long)d.b * w_bstride + part_off;
-#pragma unroll
-            for (int g = 0; g < WG; ++g) {
-                const int it = ltid + g * 256;
-                const int chunk = it & 3, row = it >> 2;
-                const int tap = row / (MT * 32), o = row - tap * (MT * 32);
-                const int tapc = min(tap, 8), oc = min(d.o_blk + o, cout - 1);
-                if (DBG != 12) wv[g] = *(const uint4*)(base + ((long)tapc * cout + oc) * cin + d.kc + chunk * 8);
-                else wv[g] = make_uint4(it, it, it, it);
-                if (d.o_blk + o >= cout) wv[g] = make_uint4(0u, 0u, 0u, 0u);
-            }
-        };
-        auto wstore = [&](const uint4 (&wv)[WG], char* lds_w) {
-#pragma unroll
-            for (int g = 0; g < WG; ++g) {
-                const int it = ltid + g * 256;
-                if (it < WITEMS) *(uint4*)(lds_w + swz(it >> 2, it & 3)) = wv[g];
             }
         };
         auto make_desc = [&](unsigned lin) {
@@ -420,14 +382,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         unsigned lin = walk.next;
         Desc d = make_desc(lin);
         Batch pre, oth;
-        uint4 wv_hi[WG], wv_lo[WG];
         build_geo(in.x[0].ld == 8);
         build_tile(d);
         issue(d, 0, pre);
-        wload(d, 0, wv_hi);
-        if (SPLIT >= 2) wload(d, w_lo_off, wv_lo);
         unsigned step = 0;
-        unsigned long long dbg_t = DBG == 6 ? clock64() : 0;
         bool more = true;
         while (more) {
             // the chunk after this one (this tile's next 32 channels, or the first chunk of the workgroup's next tile);
@@ -445,10 +403,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 dn = more ? make_desc(lin) : d;
             }
             char* px = lds + (step & 1) * STAGE_PX;
-            if (SPLIT == 1 && step) wstore(wv_lo, lds_wb);  // lo(previous chunk): the consumers are in its hi half-step
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
-                if (SPLIT == 1 && r == RA && step) lds_barrier();  // lo part of the previous chunk is in place
+                if (SPLIT == 1 && r == RA && step) lds_barrier();  // the consumers have finished the previous chunk (see below)
                 Batch& cur_b = (r & 1) ? oth : pre;
                 Batch& nxt_b = (r & 1) ? pre : oth;
                 if (r + 1 < ROUNDS) {
@@ -474,45 +431,50 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 }
             }
             if (ROUNDS & 1) pre = oth;  // the next chunk's round 0 sits in `oth` after an odd number of rounds
-            if (SPLIT == 0) wstore(wv_hi, (step & 1) ? lds_wb : lds_wa);
-            if (SPLIT == 1) wstore(wv_hi, lds_wa);
-            if (SPLIT == 2) {
-                char* slab = lds_wa + (step & 1) * 2 * WSLAB;
-                wstore(wv_hi, slab);
-                wstore(wv_lo, slab + WSLAB);
-            }
-            if (SPLIT == 3) {
-                lds_barrier();  // the consumers have finished the previous chunk: the single slab pair is free
-                wstore(wv_hi, lds_wa);
-                wstore(wv_lo, lds_wb);
-            }
-            if (SPLIT == 1) wload(d, w_lo_off, wv_lo);  // stored at the start of the next chunk (or by the tail below)
-            wload(dn, 0, wv_hi);
-            if (SPLIT >= 2) wload(dn, w_lo_off, wv_lo);
-            const unsigned long long tb = DBG == 6 ? clock64() : 0;
-            lds_barrier();  // pixel stage and (hi) slab of chunk `step` are in place
-            if (DBG == 6 && blockIdx.x == 0 && tid == 256) {
-                const unsigned long long tc = clock64();
-                atomicAdd(&g_dbg_cycles[5], tb - dbg_t);
-                atomicAdd(&g_dbg_cycles[6], tc - tb);
-                dbg_t = tc;
-            }
+            lds_barrier();  // pixel stage of chunk `step` is in place
             d = dn;
             ++step;
         }
-        if (SPLIT == 1) {  // low part of the very last chunk
-            wstore(wv_lo, lds_wb);
-            lds_barrier();
-        }
+        if (SPLIT == 1) lds_barrier();  // partner of the consumers' barrier after the very last chunk
         return;
     }
-    unsigned long long dbg_end = DBG == 6 ? clock64() : 0;
     unsigned step = 0;
     float* bias_lds = (float*)(lds + 2 * STAGE_PX + (SPLIT == 2 ? 4 : 2) * WSLAB);  // [cout], zeros without a bias
     float* slope_lds = bias_lds + cout;  // [cout] negative slopes: PReLU's, 0.2 for LeakyReLU, 1 without activation
     for (int i = tid; i < cout; i += 256) {
         bias_lds[i] = ep.bias ? ep.bias[i] : 0.f;
         slope_lds[i] = ep.slope ? ep.slope[i] : (ep.lrelu ? 0.2f : 1.0f);
+    }
+    // Weight slabs: rows (tap, o) x 32 channels of [B][9][cout][cin], L2-resident, copied global -> LDS by the MFMA waves
+    // with global_load_lds_dwordx4 (no registers, no ds_write; the loaders -- the busier half of the workgroup -- carried
+    // them through 36-72 registers before and spilled).  One instruction writes 1 KiB = 16 slab rows in lane order, so
+    // the XOR swizzle of the LDS image is applied to the SOURCE address: lane l fills 16-byte slot l & 3 of row l >> 2,
+    // which holds channel group (l & 3) ^ ((row >> 2) & 3).  Rows of a thin layer beyond cout repeat the last row: an
+    // output row depends on its own weight row only and the epilogue never stores those rows.
+    auto slab_dma = [&](int sb, int so_blk, int skc, long part_off, char* lds_slab) {
+        constexpr int NI = 9 * MT * 32 / 16;  // 1 KiB pieces per slab
+        const bf16_t* base = wts + (long)sb * w_bstride + part_off;
+#pragma unroll
+        for (int jj = 0; jj < (NI + 3) / 4; ++jj) {
+            const int j = jj * 4 + wave;
+            if (j < NI) {
+                const int row = j * 16 + (lane >> 2);
+                const int cgrp = (lane & 3) ^ ((row >> 2) & 3);
+                const int tap = row / (MT * 32), o = row - tap * (MT * 32);
+                const int oc = min(so_blk + o, cout - 1);
+                glds16(base + ((long)tap * cout + oc) * cin + skc + cgrp * 8, lds_slab + j * 1024);
+            }
+        }
+    };
+    {  // slabs of the workgroup's very first chunk
+        const TileId t0 = decode_tile<MT>(walk.next, tiles, tilesx, B);
+        if (SPLIT == 2) {
+            slab_dma(t0.b, t0.o_blk, 0, 0, lds_wa);
+            slab_dma(t0.b, t0.o_blk, 0, w_lo_off, lds_wa + WSLAB);
+        } else {
+            slab_dma(t0.b, t0.o_blk, 0, 0, lds_wa);
+            if (SPLIT == 1) slab_dma(t0.b, t0.o_blk, 0, w_lo_off, lds_wb);
+        }
     }
     for (unsigned lin = walk.next; lin < walk.end; lin += walk.stride) {
         const TileId t = decode_tile<MT>(lin, tiles, tilesx, B);
@@ -539,7 +501,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int m = 0; m < MT; ++m) {
                 const int wo = swz(tap * (MT * 32) + m * 32 + r, chunk);
                 f.a[m] = *(const short8*)(cur_w + wo);
-                if (SPLIT >= 2) f.a2[m] = *(const short8*)(cur_w2 + wo);
+                if (SPLIT) f.a2[m] = *(const short8*)(cur_w2 + wo);
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -553,7 +515,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
-                    if (SPLIT >= 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a2[m], f.b[n], acc[m][n], 0, 0, 0);
+                    if (SPLIT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a2[m], f.b[n], acc[m][n], 0, 0, 0);
                 }
         };
         auto multiply = [&](const char* cur_px, const char* cur_w, const char* cur_w2) {
@@ -579,36 +541,36 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         };
         for (int c = 0; c < nchunks; ++c) {
             const char* cur_px = lds + (step & 1) * STAGE_PX;
-            const unsigned long long t0 = DBG == 6 ? clock64() : 0;
-            __syncthreads();  // chunk `step`: pixel stage and (hi) slab are in place; the previous chunk is consumed
-            if (DBG == 6) {
-                const unsigned long long t1 = clock64();
-                multiply(cur_px, lds_wa, nullptr);
-                const unsigned long long t2 = clock64();
+            // where the NEXT chunk's weights come from (this tile's next 32 channels or the next tile's first chunk)
+            const bool last_c = c + 1 == nchunks;
+            const bool have_next = !last_c || lin + walk.stride < walk.end;
+            int nb = b, no = o_blk;
+            if (last_c && have_next) {
+                const TileId tn = decode_tile<MT>(lin + walk.stride, tiles, tilesx, B);
+                nb = tn.b;
+                no = tn.o_blk;
+            }
+            const int nkc = last_c ? 0 : (c + 1) * 32;
+            __syncthreads();  // chunk `step`: pixel stage in place (loaders), own slab DMA drained (vmcnt), previous chunk consumed
+            if (SPLIT == 1) {
+                // one slab pair [hi][lo] (four slabs of 36 KB do not fit next to the two pixel stages at MT = 2): the next
+                // chunk's slabs can only be requested once every MFMA wave has finished this chunk -- second barrier
+                multiply(cur_px, lds_wa, lds_wb);
                 lds_barrier();
-                const unsigned long long t3 = clock64();
-                multiply(cur_px, lds_wb, nullptr);
-                const unsigned long long t4 = clock64();
-                if (blockIdx.x == 0 && tid == 0) {
-                    atomicAdd(&g_dbg_cycles[0], t1 - t0);
-                    atomicAdd(&g_dbg_cycles[1], t2 - t1);
-                    atomicAdd(&g_dbg_cycles[2], t3 - t2);
-                    atomicAdd(&g_dbg_cycles[3], t4 - t3);
-                    atomicAdd(&g_dbg_cycles[4], t0 - dbg_end);
-                    atomicAdd(&g_dbg_cycles[7], 1ull);
+                if (have_next) {
+                    slab_dma(nb, no, nkc, 0, lds_wa);
+                    slab_dma(nb, no, nkc, w_lo_off, lds_wb);
                 }
-                dbg_end = t4;
-            } else if (SPLIT == 1) {
-                multiply(cur_px, lds_wa, nullptr);
-                lds_barrier();  // lo slab of this chunk is in place
-                multiply(cur_px, lds_wb, nullptr);
             } else if (SPLIT == 2) {
+                char* nslab = lds_wa + ((step + 1) & 1) * 2 * WSLAB;
+                if (have_next) {
+                    slab_dma(nb, no, nkc, 0, nslab);
+                    slab_dma(nb, no, nkc, w_lo_off, nslab + WSLAB);
+                }
                 const char* slab = lds_wa + (step & 1) * 2 * WSLAB;
                 multiply(cur_px, slab, slab + WSLAB);
-            } else if (SPLIT == 3) {
-                lds_barrier();  // both slabs of this chunk are in place (the barrier above released them to the loaders)
-                multiply(cur_px, lds_wa, lds_wb);
             } else {
+                if (have_next) slab_dma(nb, no, nkc, 0, ((step + 1) & 1) ? lds_wb : lds_wa);
                 multiply(cur_px, (step & 1) ? lds_wb : lds_wa, nullptr);
             }
             ++step;
@@ -732,24 +694,23 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
     return true;
 }
 
-template <int MT, bool BANDS, int SPLIT, int DBG = 0>
+template <int MT, bool BANDS, int SPLIT>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
     const size_t ldsb = 2 * (size_t)NPIX * 64 + (SPLIT == 2 ? 4 : 2) * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
-    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT, DBG>);  // per device
+    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
     if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-    conv3x3_mfma_bf16<MT, BANDS, SPLIT, DBG><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk);
+    conv3x3_mfma_bf16<MT, BANDS, SPLIT><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
 
 int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
-int g_conv_dbg = 0;  // 6: the cycle-counting instance of the split MT = 2 kernel (tools/bench_ops.py conv_ab)
 int g_split_two_pass = 0;  // A/B hook: two half-steps per chunk also where the fused form fits (MT = 1)
 
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
@@ -760,11 +721,7 @@ int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float
         if (wlo % 8 != 0) return SR_ERR_ARG;
 #define SR_MFMA(MT, BANDS, SPLIT) launch_mfma<MT, BANDS, SPLIT>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
         if (in.bands) {
-            if (wlo && two && g_conv_dbg == 6) return launch_mfma<2, true, 1, 6>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
-#define SR_DBGV(V) if (wlo && g_conv_dbg == V) return two ? launch_mfma<2, true, 1, V>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st) : launch_mfma<1, true, 2, V>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
-            SR_DBGV(11) SR_DBGV(12) SR_DBGV(13) SR_DBGV(14) SR_DBGV(15)
-#undef SR_DBGV
-            if (wlo) return two ? (g_split_two_pass == 3 ? SR_MFMA(2, true, 3) : SR_MFMA(2, true, 1)) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
+            if (wlo) return two ? SR_MFMA(2, true, 1) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
             return two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
         }
         if (wlo) return two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);
@@ -800,10 +757,3 @@ extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, c
 extern "C" void sr_debug_force_generic_conv(int on) { sr::g_force_generic = on; }
 
 extern "C" void sr_debug_split_two_pass(int on) { sr::g_split_two_pass = on; }
-extern "C" void sr_debug_conv_variant(int v) { sr::g_conv_dbg = v; }
-// timing experiment: read (and clear) the cycle counters of the DBG == 6 kernel
-extern "C" int sr_debug_conv_cycles(unsigned long long* out8) {
-    unsigned long long z[8] = {};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sr::g_dbg_cycles), sizeof(z)) != hipSuccess) return -3;
-    return hipMemcpyToSymbol(HIP_SYMBOL(sr::g_dbg_cycles), z, sizeof(z)) == hipSuccess ? 0 : -3;
-}

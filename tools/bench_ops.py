@@ -82,17 +82,7 @@ def conv(cin=64, cout=32, H=512, W=512, B=16, reps=10, bands=1, blocked=0, split
     def run():
         L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), gates.data_ptr(), wd.data_ptr(), 9 * cout * cin,
                                B * 9 * cout * cin if split else 0, cout, C.byref(ep), mk(out), st))
-    lib.sr_debug_conv_variant(variant)
-    cyc = (C.c_ulonglong * 8)()
-    lib.sr_debug_conv_cycles(cyc)
     t = timeit(run, reps)
-    lib.sr_debug_conv_variant(0)
-    if variant == 6:
-        torch.cuda.synchronize()
-        lib.sr_debug_conv_cycles(cyc)
-        n = max(cyc[7], 1)
-        print('  per chunk (cycles, 100 MHz-independent s_memtime ticks): consumer wait %.0f  hi %.0f  mid wait %.0f  lo %.0f  epilogue/tile-setup %.0f | '
-              'loader stage %.0f  loader wait %.0f  (%d chunks)' % tuple([cyc[i] / n for i in range(7)] + [n]))
     px = B * H * W
     byts = px * ((4 if bands else 1) * cin * 2 + (16 if bands else 0) + cout * 2)
     print('conv %d->%d %dx%d B=%d bands=%d blocked=%d split=%d variant=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic' %
