@@ -277,6 +277,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         // of a chunk's 25.5k cycles in the loader with the pipeline restarted per chunk).
         // The loaders move pixels only; the weight slabs are fetched by the MFMA waves themselves (LDS-DMA, below).
         const int ltid = tid - 256;
+        // the loaders are the pole of the workgroup and, as waves 4-7, lose the age-based issue arbitration against their
+        // SIMD partners: static priority for them (A/B: -3.5 % on the Cout = 32 layers, nothing at Cout = 64)
+        __builtin_amdgcn_s_setprio(2);
         constexpr int G = BANDS ? 2 : 5;
         constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
         constexpr int RA = ROUNDS / 2;  // rounds ahead of the mid barrier (SPLIT = 1)
@@ -674,6 +677,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
     }
 }
 
+int g_split_two_pass = 0;  // A/B hook (sr_debug_split_two_pass): experiments in tools/bench_ops.py
+
 static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const View& out, const void* wts,
                           long wbs) {
     const bool thin = cout <= 16;  // HBM-bound anyway: the unused output rows of the 32-wide tile cost nothing that matters
@@ -711,7 +716,6 @@ static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates
 }
 
 int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
-int g_split_two_pass = 0;  // A/B hook: two half-steps per chunk also where the fused form fits (MT = 1)
 
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
                    long wlo, int cout, const Epilogue& ep, View out, hipStream_t st) {
@@ -721,7 +725,7 @@ int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float
         if (wlo % 8 != 0) return SR_ERR_ARG;
 #define SR_MFMA(MT, BANDS, SPLIT) launch_mfma<MT, BANDS, SPLIT>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
         if (in.bands) {
-            if (wlo) return two ? SR_MFMA(2, true, 1) : (g_split_two_pass ? SR_MFMA(1, true, 1) : SR_MFMA(1, true, 2));
+            if (wlo) return two ? SR_MFMA(2, true, 1) : SR_MFMA(1, true, 2);
             return two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
         }
         if (wlo) return two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);
