@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsr_amd.so')
+# SR_AMD_LIB: an alternative build of the same library (A/B experiments; never a different implementation)
+LIB_PATH = os.environ.get('SR_AMD_LIB') or os.path.join(_HERE, 'libsr_amd.so')
 
 SR_F32, SR_BF16 = 0, 1
 SR_MAX_SEG = 8

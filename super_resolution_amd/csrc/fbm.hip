@@ -72,10 +72,18 @@ static int factorize(int n, int* rad) {
     return nf;
 }
 
-static int pairs_per_group(int n) {
+// complex signals (channel pairs) per workgroup: the largest power of two (<= 16) whose `nbuf` LDS buffers of n points
+// plus the twiddle table fit 160 KiB.  More signals per workgroup mean longer contiguous runs in the intermediate tensors
+// (a run is P x 8 bytes) and more butterflies per pass and barrier; measured at 2088 x 2128 x 64 channels, batch 8:
+// P = 1 / 1 (the old 32 KiB-per-buffer cap) 144 ms, P = 4 rows / 2 columns 96 ms.  `cap` (points per buffer) overrides.
+static int pairs_per_group(int n, int nbuf, int cap) {
     int p = 16;
-    while (p > 1 && (long)n * p > 4096) p >>= 1;
+    while (p > 1 && ((size_t)(nbuf * p + 1) * n * sizeof(float2) > 160ul * 1024 || (cap > 0 && (long)n * p > cap))) p >>= 1;
     return p;
+}
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && atoi(e) > 0 ? atoi(e) : dflt;  // 0: no override
 }
 
 // ---- device: Stockham pass -----------------------------------------------------------------
@@ -131,6 +139,76 @@ __device__ __forceinline__ void fft_pass_pp(const float2* __restrict__ src, floa
         float2* dp = dst + o * P + pg * PP;
 #pragma unroll
         for (int i = 0; i < PP; ++i) dp[i] = acc[i];
+    }
+}
+
+// Odd prime radices beyond 7 (config 3's 2088 = 8 * 9 * 29 and 2128 = 16 * 7 * 19 point sides): each work item produces
+// the output pair (u, R - u) of one butterfly of one signal.  With the twiddled operands z_t = x_t w^(t k tstep),
+//   X[u], X[R-u] = z_0 + sum_{t=1}^{(R-1)/2} (z_t + z_{R-t}) cos(2 pi u t / R)  -/+  i (z_t - z_{R-t}) sin(2 pi u t / R)
+// (signs for the forward transform): (R - 1) / 2 real-coefficient terms for two outputs instead of R complex terms for
+// one -- a quarter of the multiplications and half of the LDS reads of fft_pass_pp, with (R + 1) / 2 work items per
+// butterfly (1080 for a 2088-point signal, where whole butterflies would leave 72).
+template <bool INV>
+__device__ __forceinline__ void fft_pass_prime(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
+                                               int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+    const int NR = N / R;
+    const int tstep = NR / Ns;
+    const int half = (R + 1) / 2;  // outputs u = 0 .. half-1 (u = 0 pairs with itself)
+    for (int it = threadIdx.x; it < NR * half * P; it += blockDim.x) {
+        const int p = it % P;
+        const int o = it / P;
+        const int u = o % half;
+        const int j = o / half;
+        const int jhi = j / Ns, k = j - jhi * Ns;
+        const int ks = k * tstep;  // pass twiddle of operand t: tw[t * ks], t * ks < N
+        float2 z0 = src[j * P + p];
+        if (premul) {
+            z0.x *= premul[j];
+            z0.y *= premul[j];
+        }
+        float2 a = z0, bsum = make_float2(0.f, 0.f);
+        int m = 0;      // (u * t) mod R
+        int q1 = 0, q2 = R * ks;  // t * ks and (R - t) * ks
+        for (int t = 1; t < half; ++t) {
+            m += u;
+            if (m >= R) m -= R;
+            q1 += ks;
+            q2 -= ks;
+            float2 w1 = tw[q1], w2 = tw[q2 >= N ? q2 - N : q2];
+            if (INV) {
+                w1.y = -w1.y;
+                w2.y = -w2.y;
+            }
+            const int s1 = j + t * NR, s2 = j + (R - t) * NR;
+            float2 x1 = src[s1 * P + p], x2 = src[s2 * P + p];
+            if (premul) {
+                const float m1 = premul[s1], m2 = premul[s2];
+                x1.x *= m1;
+                x1.y *= m1;
+                x2.x *= m2;
+                x2.y *= m2;
+            }
+            const float2 z1 = cmul(x1, w1), z2 = cmul(x2, w2);
+            const float2 cs = tw[m * NR];  // (cos, -sin) of 2 pi u t / R
+            a.x += (z1.x + z2.x) * cs.x;
+            a.y += (z1.y + z2.y) * cs.x;
+            bsum.x += (z1.x - z2.x) * cs.y;
+            bsum.y += (z1.y - z2.y) * cs.y;
+        }
+        // forward: X[u] = a - i * (-b') with b' = sum d * (-sin) -> X[u] = a + i * bsum rotated; written out explicitly:
+        // e^{-i th} -> z1 (cos - i sin) + z2 (cos + i sin) = (z1 + z2) cos - i (z1 - z2) sin; cs.y = -sin, so
+        // -i (z1 - z2) sin = i (z1 - z2) cs.y = i * bsum-term.  i * (x + i y) = (-y, x).
+        float2 up, um;
+        if (!INV) {
+            up = make_float2(a.x - bsum.y, a.y + bsum.x);  // X[u]
+            um = make_float2(a.x + bsum.y, a.y - bsum.x);  // X[R - u]
+        } else {
+            up = make_float2(a.x + bsum.y, a.y - bsum.x);
+            um = make_float2(a.x - bsum.y, a.y + bsum.x);
+        }
+        float2* dp = dst + (jhi * R * Ns + k) * P + p;
+        dp[u * Ns * P] = up;
+        if (u) dp[(R - u) * Ns * P] = um;
     }
 }
 
@@ -220,7 +298,9 @@ __device__ __forceinline__ void fft_pass_r(const float2* __restrict__ src, float
         case 4: fft_pass_bfly<INV, PP, 4>(src, dst, N, Ns, P, tw, premul); break;
         case 5: fft_pass_bfly<INV, PP, 5>(src, dst, N, Ns, P, tw, premul); break;
         case 7: fft_pass_bfly<INV, (PP < 2 ? PP : 2), 7>(src, dst, N, Ns, P, tw, premul); break;  // 7 x PP operands in registers
-        default: fft_pass_pp<INV, PP>(src, dst, N, R, Ns, P, tw, premul);  // larger prime factors: one output per item
+        default:
+            if (R & 1) fft_pass_prime<INV>(src, dst, N, R, Ns, P, tw, premul);  // odd primes: conjugate output pairs
+            else fft_pass_pp<INV, PP>(src, dst, N, R, Ns, P, tw, premul);
     }
 }
 
@@ -380,8 +460,9 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
     const int nk[3] = {n2, n4, n8};
     const int* ck[3] = {cols2, cols4, cols8};
     const float2* ys[3] = {y2, y4, y8};
-    const View outs[3] = {l2, l4, l8};
     for (int k = 0; k < 3; ++k) {
+        // selected field by field: an array of View structs indexed by the runtime k lived in scratch memory (128 B per lane)
+        const View out = k == 0 ? l2 : (k == 1 ? l4 : l8);
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) bufA[it] = make_float2(0.f, 0.f);
         __syncthreads();
         const float2* yr = ys[k] + ((long)b * H + h) * nk[k] * PT;
@@ -399,10 +480,10 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
             const float2 v = res[it];
             const long pix = (long)h * W + w;
             if (pair) {
-                if (c < C) PairIO<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c), make_float2(v.x * norm, v.y * norm));
+                if (c < C) PairIO<T>::st((T*)out.p + voff(out, b, pix, c), make_float2(v.x * norm, v.y * norm));
             } else {
-                if (c < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c), v.x * norm);
-                if (c + 1 < C) Elem<T>::st((T*)outs[k].p + voff(outs[k], b, pix, c + 1), v.y * norm);
+                if (c < C) Elem<T>::st((T*)out.p + voff(out, b, pix, c), v.x * norm);
+                if (c + 1 < C) Elem<T>::st((T*)out.p + voff(out, b, pix, c + 1), v.y * norm);
             }
         }
         __syncthreads();
@@ -507,8 +588,8 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
     pl->W = W;
     pl->nfW = factorize(W, pl->radW);
     pl->nfH = factorize(H, pl->radH);
-    pl->Pw = pairs_per_group(W);
-    pl->Ph = pairs_per_group(H);
+    pl->Pw = pairs_per_group(W, 2, env_int("SR_AMD_GENERIC_CAP_W", 0));
+    pl->Ph = pairs_per_group(H, 3, env_int("SR_AMD_GENERIC_CAP_H", 0));
     const int wh = W / 2 + 1;
     std::vector<uint8_t> rows(3 * H), cols(3 * wh);
     resized_masks(H, W, rows.data(), cols.data());
