@@ -83,11 +83,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 __host__ __device__ inline int mods_stride(int cin, int cout) { return (2 * cin + cout + 9 + KN + 3) & ~3; }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp, int B,
-                                                   float momentum, float* __restrict__ mods) {
+__global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp, int Btot,
+                                                   int bpb, float momentum, float* __restrict__ mods) {
     extern __shared__ float sh[];
     const int cin = lp.cin, cout = lp.cout;
     const int ms = mods_stride(cin, cout);
+    // this workgroup's samples: all of them in train mode (BatchNorm couples the batch), `bpb` per workgroup otherwise
+    // (running statistics: samples are independent, and a kernel of one workgroup is a chain of dependent memory round
+    // trips -- 184 us for 16 samples in one workgroup)
+    const int b0 = blockIdx.x * bpb;
+    const int B = min(bpb, Btot - b0);
+    pooled += (long)b0 * pooled_ld;
+    mods += (long)b0 * ms;
     float* z = sh;                 // [B][ATT] fc outputs, then StarReLU activations
     float* mean = z + B * ATT;     // [ATT]
     float* var = mean + ATT;       // [ATT]
@@ -214,16 +221,14 @@ int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const
     if (lp.loc_taps > 15) return SR_ERR_ARG;
     if (train && (B < 2 || B > KSM_MAX_B)) return SR_ERR_ARG;  // BatchNorm needs more than one value per channel
     const int ms = mods_stride(lp.cin, lp.cout);
-    for (int b0 = 0; b0 < B; b0 += KSM_MAX_B) {
-        const int nb = B - b0 < KSM_MAX_B ? B - b0 : KSM_MAX_B;
-        const size_t sh = ((size_t)nb * ATT + 2 * ATT) * sizeof(float);
-        const int threads = nb >= 4 ? 1024 : 256;
-        if (train)
-            ksm_kernel<true><<<1, threads, sh, st>>>(pooled + (long)b0 * pooled_ld, pooled_ld, lp, nb, momentum, mods + (long)b0 * ms);
-        else
-            ksm_kernel<false><<<1, threads, sh, st>>>(pooled + (long)b0 * pooled_ld, pooled_ld, lp, nb, momentum, mods + (long)b0 * ms);
-        SR_LAUNCH_CHECK();
+    if (train) {
+        const size_t sh = ((size_t)B * ATT + 2 * ATT) * sizeof(float);
+        ksm_kernel<true><<<1, B >= 4 ? 1024 : 256, sh, st>>>(pooled, pooled_ld, lp, B, B, momentum, mods);
+    } else {
+        const size_t sh = (3 * ATT) * sizeof(float);
+        ksm_kernel<false><<<B, 256, sh, st>>>(pooled, pooled_ld, lp, B, 1, momentum, mods);
     }
+    SR_LAUNCH_CHECK();
     dim3 grid(cdiv((long)lp.cout * lp.cin, 256), B);
     if (dtype == SR_F32)
         aggregate_kernel<float><<<grid, 256, 0, st>>>(mods, lp, (float*)wdyn, (float*)wdyn_lo);
