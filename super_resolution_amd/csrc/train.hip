@@ -185,30 +185,41 @@ __global__ __launch_bounds__(256) void fbm_backward_kernel(long total_pix, long 
 
 // ---------------------------------------------------------------------------------------------
 // input-gradient assembly: dx = dx_direct + a2 + a4 + a8 + sum_{k,t} gw[k][c][t] dz_k[p - off(t)] + dpooled[b][c] / (H W)
+// lane <-> channel (the 27 gate weights of the channel stay in registers), a wavefront walks a run of pixels; the nine
+// neighbouring logit gradients of a pixel are the same address for all lanes (one broadcast load each).
 template <typename T>
 __global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, int C, const float* __restrict__ dz, sr_layer_params lp,
                                                          View dxd, View a2, View a4, View a8, const float* __restrict__ dpooled,
-                                                         int dpooled_ld, View out) {
-    const long npix = (long)H * W, total = (long)B * npix * C;
+                                                         int dpooled_ld, View out, int pix_per_wave) {
+    const long npix = (long)H * W, total = (long)B * npix;
     const float inv = 1.0f / (float)npix;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long pg = i / C;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.y * 64 + lane;
+    const bool live = c < C;
+    const int cc = live ? c : C - 1;
+    float gw[3][9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gw[k][t] = lp.gate_w[k][cc * 9 + t];
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long q0 = wave * pix_per_wave, q1 = min(total, q0 + pix_per_wave);
+    for (long pg = q0; pg < q1; ++pg) {
         const int b = (int)(pg / npix);
         const long p = pg - (long)b * npix;
         const int h = (int)(p / W), w = (int)(p - (long)h * W);
-        float v = Elem<T>::ld((const T*)dxd.p + voff(dxd, b, p, c)) + Elem<T>::ld((const T*)a2.p + voff(a2, b, p, c)) +
-                  Elem<T>::ld((const T*)a4.p + voff(a4, b, p, c)) + Elem<T>::ld((const T*)a8.p + voff(a8, b, p, c));
-        if (dpooled) v += dpooled[(long)b * dpooled_ld + c] * inv;
+        float v = Elem<T>::ld((const T*)dxd.p + voff(dxd, b, p, cc)) + Elem<T>::ld((const T*)a2.p + voff(a2, b, p, cc)) +
+                  Elem<T>::ld((const T*)a4.p + voff(a4, b, p, cc)) + Elem<T>::ld((const T*)a8.p + voff(a8, b, p, cc));
+        if (dpooled) v += dpooled[(long)b * dpooled_ld + cc] * inv;
         float gsum = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
-            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;  // wave-uniform
             const float4 d = ((const float4*)dz)[(long)b * npix + (long)hh * W + ww];
-            gsum += lp.gate_w[0][c * 9 + t] * d.x + lp.gate_w[1][c * 9 + t] * d.y + lp.gate_w[2][c * 9 + t] * d.z;
+            gsum += gw[0][t] * d.x + gw[1][t] * d.y + gw[2][t] * d.z;
         }
-        Elem<T>::st((T*)out.p + voff(out, b, p, c), v + gsum);
+        if (live) Elem<T>::st((T*)out.p + voff(out, b, p, c), v + gsum);
     }
 }
 
@@ -317,7 +328,7 @@ extern "C" int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat*
     if (dbias) {
         SR_HIP(hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), st));
         const long total = (long)B * npix;
-        const int ppb = 2048;
+        const int ppb = 256;
         if (dtype == SR_F32)
             bias_grad_kernel<float><<<cdiv(total, ppb), 256, 0, st>>>(dyv, npix, total, cout, dbias, ppb);
         else
@@ -360,14 +371,14 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
     hipStream_t st = (hipStream_t)stream;
     SR_HIP(hipMemsetAsync(dgate_w, 0, (size_t)27 * C * sizeof(float), st));
     SR_HIP(hipMemsetAsync(dgate_b, 0, 3 * sizeof(float), st));
-    const long n = total * C;
-    const int g1 = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
-    const int ppb = 1024;
+    const int ppw = 16;  // pixels per wavefront
+    dim3 g1(cdiv(total, 4 * ppw), cdiv(C, 64));
+    const int ppb = 128;  // 32 pixels per wavefront: the kernel is a chain of dependent loads, parallelism is what hides them
     dim3 g2(cdiv(total, ppb), cdiv(C, 64));
 #define SR_GB(T)                                                                                                                 \
     do {                                                                                                                         \
         input_grad_kernel<T><<<g1, 256, 0, st>>>(B, H, W, C, dlogits, *lp, to_view(dx_direct, npix), to_view(a2, npix),         \
-                                                 to_view(a4, npix), to_view(a8, npix), dpooled, dpooled_ld, to_view(dx_out, npix)); \
+                                                 to_view(a4, npix), to_view(a8, npix), dpooled, dpooled_ld, to_view(dx_out, npix), ppw); \
         SR_LAUNCH_CHECK();                                                                                                       \
         gate_wgrad_kernel<T><<<g2, 256, 0, st>>>(B, H, W, C, to_view(x, npix), dlogits, dgate_w, dgate_b, ppb);                  \
         SR_LAUNCH_CHECK();                                                                                                       \

@@ -220,7 +220,6 @@ int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const
                      void* wdyn, void* wdyn_lo, float* mods, hipStream_t st) {
     if (lp.loc_taps > 15) return SR_ERR_ARG;
     if (train && (B < 2 || B > KSM_MAX_B)) return SR_ERR_ARG;  // BatchNorm needs more than one value per channel
-    const int ms = mods_stride(lp.cin, lp.cout);
     if (train) {
         const size_t sh = ((size_t)B * ATT + 2 * ATT) * sizeof(float);
         ksm_kernel<true><<<1, B >= 4 ? 1024 : 256, sh, st>>>(pooled, pooled_ld, lp, B, B, momentum, mods);

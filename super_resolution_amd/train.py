@@ -80,19 +80,23 @@ _WEIGHT_PATH = ('dft_weight', 'KSM_Global.fc.weight', 'KSM_Global.bn.weight', 'K
 # helpers
 # ------------------------------------------------------------------------------------------------------------------
 def _pack(x):
+    """(B, C, H, W) tensor -> contiguous (B, H, W, C) tensor the kernels read.  The layers hand each other NCHW-shaped
+    tensors in torch's channels_last memory format -- which IS NHWC memory -- so between two layers of the network this is
+    a view; only tensors that arrive in the default format (the network input, a loss gradient) are converted, by
+    sr_pack_nchw.  (Converting at every layer boundary took 119 ms of the 2.1 s training step.)"""
     B, Cc, H, W = x.shape
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
     xn = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
     code = L.dtype_code(x.dtype)
-    L.check(L.lib().sr_pack_nchw(x.data_ptr(), code, xn.data_ptr(), code, B, Cc, H, W, 1, L.stream_ptr(x.device)), 'sr_pack_nchw')
+    L.check(L.lib().sr_pack_nchw(x.contiguous().data_ptr(), code, xn.data_ptr(), code, B, Cc, H, W, 1, L.stream_ptr(x.device)), 'sr_pack_nchw')
     return xn
 
 
 def _unpack(xn):
-    B, H, W, Cc = xn.shape
-    x = torch.empty(B, Cc, H, W, dtype=xn.dtype, device=xn.device)
-    code = L.dtype_code(xn.dtype)
-    L.check(L.lib().sr_unpack_nhwc(xn.data_ptr(), code, x.data_ptr(), code, B, Cc, H, W, L.stream_ptr(xn.device)), 'sr_unpack_nhwc')
-    return x
+    """(B, H, W, C) kernel output -> the same memory as an NCHW-shaped channels_last tensor (no copy)."""
+    return xn.permute(0, 3, 1, 2)
 
 
 def _concat1(xn, bands=None):
@@ -133,7 +137,7 @@ class _PlainConvFn(torch.autograd.Function):
         lib, dev = L.lib(), x.device
         cout, cin = weight.shape[:2]
         with torch.cuda.device(dev):
-            xn = _pack(x.contiguous())
+            xn = _pack(x)
             wp, _ = L.pack_plain_weight(weight.detach(), torch.float32, cout, cin)
             yn = _conv(xn, _concat1(xn), None, wp, 0, cout, None if bias is None else bias.detach().data_ptr())
             y = _unpack(yn)
@@ -150,7 +154,7 @@ class _PlainConvFn(torch.autograd.Function):
         cout = dy.shape[1]
         with torch.cuda.device(dev):
             st = L.stream_ptr(dev)
-            dyn = _pack(dy.contiguous())
+            dyn = _pack(dy)
             dw = torch.empty(9, cout, cin, dtype=torch.float32, device=dev)
             db = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
             cc = _concat1(xn)
@@ -181,7 +185,7 @@ class _FDConvFn(torch.autograd.Function):
             st = L.stream_ptr(dev)
             lp, _keep = m.sr_layer_params(torch.float32)
             plan = m._plan(H, W)
-            xn = _pack(x.contiguous())
+            xn = _pack(x)
             bands = [torch.empty_like(xn) for _ in range(3)]
             pooled = torch.empty(B, cin, dtype=torch.float32, device=dev)
             ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
@@ -218,7 +222,7 @@ class _FDConvFn(torch.autograd.Function):
             st = L.stream_ptr(dev)
             lp, _keep = m.sr_layer_params(torch.float32)
             plan = m._plan(H, W)
-            dyn = _pack(dy.contiguous())
+            dyn = _pack(dy)
             # 1. weight / bias gradients of the convolution
             dw = torch.empty(B, 9, cout, cin, dtype=torch.float32, device=dev)
             db = torch.empty(cout, dtype=torch.float32, device=dev) if m.bias is not None else None
