@@ -282,7 +282,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         __builtin_amdgcn_s_setprio(2);
         constexpr int G = BANDS ? 2 : 5;
         constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
-        constexpr int RA = ROUNDS / 2;  // rounds ahead of the mid barrier (SPLIT = 1)
+        // SPLIT = 1: rounds ahead of the barrier at which the MFMA waves hand the slab pair back (late, so that the loaders
+        // rarely wait for the fused multiply; measured equal to the half-way position: the MFMA waves are the pole there)
+        constexpr int RA = ROUNDS - 1;
         struct Batch {
             uint4 vx[G], a2[G], a4[G], a8[G];
             float4 gg[G];
