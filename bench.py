@@ -365,6 +365,8 @@ def run_train(args, world, rank, dev, dist):
     torch.manual_seed(1234)
     net = replace_conv_with_fdconv(RRDBNet(1, 1, 4, NUM_FEAT, NUM_BLOCK, NUM_GROW)).to(dev)
     net.train()
+    mixed = args.train_dtype == 'bf16'
+    net.compute_dtype = torch.bfloat16 if mixed else None
     B, hr = args.train_batch, args.train_hr
     lr_side = hr // 4
     g = torch.Generator().manual_seed(4321 + rank)
@@ -400,15 +402,16 @@ def run_train(args, world, rank, dev, dist):
         'metric': 'output Mpix/s (4x SR) at 1/2/4/8 MI355X; conv MFMA util %',
         'value': world * B * hr * hr / 1e6 / step_s, 'unit': 'output Mpix/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': max(args.warmup, 1), 'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'bf16' if mixed else 'f32', 'data': 'synthetic',
         'config': {'workload': 'training step of RRDBNet-FDConv(1,1,64,23,32): %d HR crops of %dx%d per GPU (LR %dx%d), train-mode '
-                               'forward + bilinear/L1 loss + backward + gradient all-reduce + Adam, float32 '
-                               '(BASELINE.json configs[3], L1 term of the owner script)' % (B, hr, hr, lr_side, lr_side),
+                               'forward + bilinear/L1 loss + backward + gradient all-reduce + Adam, %s '
+                               '(BASELINE.json configs[3], L1 term of the owner script)'
+                               % (B, hr, hr, lr_side, lr_side, 'bf16 activations on MFMA, float32 parameters / weight gradients / Adam' if mixed else 'float32'),
                    'global_batch': world * B, 'samples_per_s': world * B / step_s,
                    'parallelism': 'data parallel x%d, bucketed gradient all-reduce of %.1f M parameters (local BatchNorm statistics)' % (world, nparam / 1e6),
                    'loss_first_last': [losses[0], losses[-1]], 'loss_finite': bool(np.isfinite(losses).all()),
                    'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv forward + operand gradient + weight gradient (fp32 VALU kernels in this stage)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv forward + operand gradient (MFMA in bf16 mode) + weight gradient (fp32-accumulate VALU kernel)',
                      'achieved': flops / step_s / 1e12, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
                      'note': 'whole-step time (no per-kernel events in the training path yet); algorithmic conv FLOPs = 3 x forward'},
@@ -424,6 +427,7 @@ def main():
     ap.add_argument('--frames', type=int, default=4, help='srvgg: 1080p frames per step')
     ap.add_argument('--train-batch', type=int, default=32, help='train: HR crops per GPU and step')
     ap.add_argument('--train-hr', type=int, default=256, help='train: side of the HR crops')
+    ap.add_argument('--train-dtype', choices=('bf16', 'f32'), default='bf16', help='train: bf16 = mixed precision (bf16 activations on the matrix cores, float32 parameters and weight gradients); f32 = the parity path')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')

@@ -224,7 +224,10 @@ __global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, in
 }
 
 // gate-conv weight / bias gradients: workgroup = 64 channels x a run of pixels; lane <-> channel, the 4 waves take
-// interleaved pixels; dgw[k][c][t] += x[q][c] * dz_k[q - off(t)]
+// interleaved pixels; dgw[k][c][t] += x[q][c] * dz_k[q - off(t)].  The body is branch-free (clamped neighbour address,
+// validity as a factor) and unrolled four pixels deep so that the loads of several pixels are in flight: the kernel is a
+// stream of dependent-looking loads otherwise.  Few, long runs per workgroup: every workgroup ends in 27 x 64 atomics on
+// the same 27 x C addresses (1024 workgroups per channel tile spent their time queueing there: 662 us).
 template <typename T>
 __global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, int C, View x, const float* __restrict__ dz,
                                                          float* __restrict__ dgw, float* __restrict__ dgb, int pix_per_block) {
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, in
     const long npix = (long)H * W, total = (long)B * npix;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + lane;
+    const int cc = c < C ? c : C - 1;
     const long q0 = (long)blockIdx.x * pix_per_block, q1 = min(total, q0 + pix_per_block);
     float acc[3][9];
 #pragma unroll
@@ -239,12 +243,14 @@ __global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, in
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[k][t] = 0.f;
     float bsum[3] = {0.f, 0.f, 0.f};
+    const bool do_bias = blockIdx.y == 0 && lane == 0;
+#pragma unroll 4
     for (long qg = q0 + wave; qg < q1; qg += 4) {
         const int b = (int)(qg / npix);
         const long q = qg - (long)b * npix;
         const int h = (int)(q / W), w = (int)(q - (long)h * W);
-        const float xv = c < C ? Elem<T>::ld((const T*)x.p + voff(x, b, q, c)) : 0.f;
-        if (blockIdx.y == 0 && lane == 0) {
+        const float xv = Elem<T>::ld((const T*)x.p + voff(x, b, q, cc));
+        if (do_bias) {
             const float4 d = ((const float4*)dz)[qg];
             bsum[0] += d.x;
             bsum[1] += d.y;
@@ -253,11 +259,13 @@ __global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, in
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
-            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-            const float4 d = ((const float4*)dz)[(long)b * npix + (long)hh * W + ww];
-            acc[0][t] += xv * d.x;
-            acc[1][t] += xv * d.y;
-            acc[2][t] += xv * d.z;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const int hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
+            const float4 d = ((const float4*)dz)[(long)b * npix + (long)hc * W + wc];
+            const float xm = ok ? xv : 0.f;
+            acc[0][t] += xm * d.x;
+            acc[1][t] += xm * d.y;
+            acc[2][t] += xm * d.z;
         }
     }
 #pragma unroll
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, in
                 atomicAdd(dgw + ((long)k * C + c) * 9 + t, red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane]);
             }
     }
-    if (blockIdx.y == 0 && lane == 0)
+    if (do_bias)
 #pragma unroll
         for (int k = 0; k < 3; ++k) atomicAdd(dgb + k, bsum[k]);
 }
@@ -373,7 +381,7 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
     SR_HIP(hipMemsetAsync(dgate_b, 0, 3 * sizeof(float), st));
     const int ppw = 16;  // pixels per wavefront
     dim3 g1(cdiv(total, 4 * ppw), cdiv(C, 64));
-    const int ppb = 128;  // 32 pixels per wavefront: the kernel is a chain of dependent loads, parallelism is what hides them
+    const int ppb = total >= 512L * 512 ? 2048 : 512;  // pixels per workgroup: ~2 workgroups per CU and channel tile at the training sizes
     dim3 g2(cdiv(total, ppb), cdiv(C, 64));
 #define SR_GB(T)                                                                                                                 \
     do {                                                                                                                         \

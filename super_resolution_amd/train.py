@@ -12,6 +12,11 @@ Here every conv layer is a `torch.autograd.Function` whose forward AND backward 
             weights), band-mix / gate backward (`sr_fbm_backward`, `sr_fbm_gates_backward`), and the three band branches
             back through `sr_fbm_lowpass` (the box low-pass is self-adjoint).
 
+Precision: float32 inputs run every kernel in float32 (the parity path: gradients match the reference's to 1e-4);
+bfloat16 inputs -- or `net.compute_dtype = torch.bfloat16` with float32 data -- run mixed precision: activations and
+their gradients in bf16 on the matrix cores (MFMA convolution forward and operand gradient with split hi + lo weights,
+MFMA low-pass), parameters, weight gradients, gates and every reduction in float32.
+
 Two things stay on torch autograd (device tensors, no CPU path):
   * the SMALL weight path -- pooled (B, Cin) -> W_b (B, 9, Cout, Cin): KSM_Global / KSM_Local / spectral scatter + irfft2
     (a few hundred KB per layer).  Its backward is torch's, on a torch restatement (`dynamic_weight`) that is recomputed
@@ -109,20 +114,34 @@ def _concat1(xn, bands=None):
     return cc
 
 
-def _conv(xn, cc, gates, w, w_bstride, cout, bias=None):
+def _conv(xn, cc, gates, w, w_bstride, cout, bias=None, w_lo=0):
+    """w_lo: elements from `w` to the low-order parts of the same weights (bf16 split weights), 0: none."""
     B, H, W, _ = xn.shape
     yn = torch.empty(B, H, W, cout, dtype=xn.dtype, device=xn.device)
     ep = L.Epilogue()
     ep.bias = bias
-    L.check(L.lib().sr_conv3x3(L.dtype_code(xn.dtype), B, H, W, C.byref(cc), L.ptr(gates), w.data_ptr(), w_bstride, 0, cout,
+    L.check(L.lib().sr_conv3x3(L.dtype_code(xn.dtype), B, H, W, C.byref(cc), L.ptr(gates), w.data_ptr(), w_bstride, w_lo, cout,
                                C.byref(ep), L.view(yn), L.stream_ptr(xn.device)), 'sr_conv3x3')
     return yn
 
 
 def _check_input(x, who):
+    """float32: the parity path (every kernel in fp32).  bfloat16: mixed precision -- activations, their gradients and the
+    conv operands in bf16 on the matrix cores (split hi + lo weights), parameters, weight gradients, gates, pooled means
+    and every reduction in float32."""
     L.require_gpu(x, who)
-    if x.dtype != torch.float32:
-        raise TypeError('%s: the training path computes in float32 (got %s)' % (who, x.dtype))
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('%s: the training path computes in float32 or bfloat16 (got %s)' % (who, x.dtype))
+
+
+def _transposed(w, nb, cout, cin):
+    """[parts][nb][9][cout][cin] -> [parts][nb][9][cin][cout] with mirrored taps, every part (hi, lo) separately."""
+    parts = w.shape[0]
+    wt = torch.empty(parts, nb, 9, cin, cout, dtype=w.dtype, device=w.device)
+    for k in range(parts):
+        L.check(L.lib().sr_conv_weight_transpose(w[k].data_ptr(), wt[k].data_ptr(), L.dtype_code(w.dtype), nb, cout, cin,
+                                                 L.stream_ptr(w.device)), 'sr_conv_weight_transpose')
+    return wt
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -138,8 +157,13 @@ class _PlainConvFn(torch.autograd.Function):
         cout, cin = weight.shape[:2]
         with torch.cuda.device(dev):
             xn = _pack(x)
-            wp, _ = L.pack_plain_weight(weight.detach(), torch.float32, cout, cin)
-            yn = _conv(xn, _concat1(xn), None, wp, 0, cout, None if bias is None else bias.detach().data_ptr())
+            # bf16: hi + lo pairs for every plain layer of the training path (the weights are what is being learned)
+            n = 9 * cout * cin
+            split = x.dtype == torch.bfloat16
+            wp = torch.empty(2 if split else 1, 1, 9, cout, cin, dtype=x.dtype, device=dev)
+            L.check(lib.sr_pack_conv_weight(weight.detach().contiguous().data_ptr(), wp[0].data_ptr(), wp[1].data_ptr() if split else None,
+                                            L.dtype_code(x.dtype), cout, cin, L.stream_ptr(dev)), 'sr_pack_conv_weight')
+            yn = _conv(xn, _concat1(xn), None, wp, 0, cout, None if bias is None else bias.detach().data_ptr(), n if split else 0)
             y = _unpack(yn)
         ctx.save_for_backward(xn, wp)
         ctx.has_bias = bias is not None
@@ -154,17 +178,16 @@ class _PlainConvFn(torch.autograd.Function):
         cout = dy.shape[1]
         with torch.cuda.device(dev):
             st = L.stream_ptr(dev)
-            dyn = _pack(dy)
+            dyn = _pack(dy.to(xn.dtype))
             dw = torch.empty(9, cout, cin, dtype=torch.float32, device=dev)
             db = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
             cc = _concat1(xn)
-            L.check(lib.sr_conv3x3_wgrad(L.SR_F32, B, H, W, C.byref(cc), None, L.view(dyn), cout, 0, dw.data_ptr(), L.ptr(db), st),
-                    'sr_conv3x3_wgrad')
+            L.check(lib.sr_conv3x3_wgrad(L.dtype_code(xn.dtype), B, H, W, C.byref(cc), None, L.view(dyn), cout, 0, dw.data_ptr(), L.ptr(db),
+                                         st), 'sr_conv3x3_wgrad')
             dx = None
             if ctx.need_dx:
-                wt = torch.empty(9, cin, cout, dtype=torch.float32, device=dev)
-                L.check(lib.sr_conv_weight_transpose(wp.data_ptr(), wt.data_ptr(), L.SR_F32, 1, cout, cin, st), 'sr_conv_weight_transpose')
-                dx = _unpack(_conv(dyn, _concat1(dyn), None, wt, 0, cin))
+                wt = _transposed(wp, 1, cout, cin)
+                dx = _unpack(_conv(dyn, _concat1(dyn), None, wt, 0, cin, None, 9 * cin * cout if wt.shape[0] == 2 else 0))
         return dx, dw.permute(1, 2, 0).reshape(cout, cin, 3, 3), db
 
 
@@ -183,27 +206,30 @@ class _FDConvFn(torch.autograd.Function):
                              % (torch.Size([B, m.KSM_Global.fc.out_channels, 1, 1]),))  # nn.BatchNorm2d's own error
         with torch.cuda.device(dev):
             st = L.stream_ptr(dev)
-            lp, _keep = m.sr_layer_params(torch.float32)
+            dt, code = x.dtype, L.dtype_code(x.dtype)
+            split = dt == torch.bfloat16
+            lp, _keep = m.sr_layer_params(dt)
             plan = m._plan(H, W)
             xn = _pack(x)
             bands = [torch.empty_like(xn) for _ in range(3)]
             pooled = torch.empty(B, cin, dtype=torch.float32, device=dev)
             ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
-            L.check(lib.sr_fbm_lowpass(plan, L.SR_F32, B, L.view(xn), 0, L.view(bands[0]), L.view(bands[1]), L.view(bands[2]),
+            L.check(lib.sr_fbm_lowpass(plan, code, B, L.view(xn), 0, L.view(bands[0]), L.view(bands[1]), L.view(bands[2]),
                                        pooled.data_ptr(), cin, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass')
             gates = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
             cc = _concat1(xn)
-            L.check(lib.sr_fbm_gates(L.SR_F32, B, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st), 'sr_fbm_gates')
-            wdyn = torch.empty(B, 9, cout, cin, dtype=torch.float32, device=dev)
+            L.check(lib.sr_fbm_gates(code, B, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st), 'sr_fbm_gates')
+            wdyn = torch.empty(2 if split else 1, B, 9, cout, cin, dtype=dt, device=dev)
             mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout), dtype=torch.uint8, device=dev)
             bn = m.KSM_Global.bn
             mom = 0.0
             if training and bn.track_running_stats:
                 bn.num_batches_tracked += 1
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            L.check(lib.sr_fdconv_weightgen(L.SR_F32, B, pooled.data_ptr(), cin, C.byref(lp), int(training), float(mom),
-                                            wdyn.data_ptr(), None, mods.data_ptr(), mods.numel(), st), 'sr_fdconv_weightgen')
-            yn = _conv(xn, _concat1(xn, bands), gates, wdyn, 9 * cout * cin, cout, lp.bias)
+            L.check(lib.sr_fdconv_weightgen(code, B, pooled.data_ptr(), cin, C.byref(lp), int(training), float(mom),
+                                            wdyn[0].data_ptr(), wdyn[1].data_ptr() if split else None, mods.data_ptr(), mods.numel(),
+                                            st), 'sr_fdconv_weightgen')
+            yn = _conv(xn, _concat1(xn, bands), gates, wdyn, 9 * cout * cin, cout, lp.bias, B * 9 * cout * cin if split else 0)
             y = _unpack(yn)
         ctx.m, ctx.training = m, training
         ctx.names = [n for n, _ in m.named_parameters()]
@@ -220,25 +246,25 @@ class _FDConvFn(torch.autograd.Function):
         grads = {}
         with torch.cuda.device(dev):
             st = L.stream_ptr(dev)
-            lp, _keep = m.sr_layer_params(torch.float32)
+            dt, code = xn.dtype, L.dtype_code(xn.dtype)
+            lp, _keep = m.sr_layer_params(dt)
             plan = m._plan(H, W)
-            dyn = _pack(dy)
+            dyn = _pack(dy.to(dt))
             # 1. weight / bias gradients of the convolution
             dw = torch.empty(B, 9, cout, cin, dtype=torch.float32, device=dev)
             db = torch.empty(cout, dtype=torch.float32, device=dev) if m.bias is not None else None
             cc = _concat1(xn, (b2, b4, b8))
-            L.check(lib.sr_conv3x3_wgrad(L.SR_F32, B, H, W, C.byref(cc), gates.data_ptr(), L.view(dyn), cout, 1, dw.data_ptr(),
+            L.check(lib.sr_conv3x3_wgrad(code, B, H, W, C.byref(cc), gates.data_ptr(), L.view(dyn), cout, 1, dw.data_ptr(),
                                          L.ptr(db), st), 'sr_conv3x3_wgrad')
             if db is not None:
                 grads['bias'] = db
             # 2. gradient wrt the modulated operand: convolution of dy with the transposed, mirrored weights
-            wt = torch.empty(B, 9, cin, cout, dtype=torch.float32, device=dev)
-            L.check(lib.sr_conv_weight_transpose(wdyn.data_ptr(), wt.data_ptr(), L.SR_F32, B, cout, cin, st), 'sr_conv_weight_transpose')
-            da = _conv(dyn, _concat1(dyn), None, wt, 9 * cin * cout, cin)
+            wt = _transposed(wdyn, B, cout, cin)
+            da = _conv(dyn, _concat1(dyn), None, wt, 9 * cin * cout, cin, None, B * 9 * cin * cout if wt.shape[0] == 2 else 0)
             # 3. band mix: four linear branches + gate logits
             dxd, dl2, dl4, dl8 = (torch.empty_like(xn) for _ in range(4))
             dz = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
-            L.check(lib.sr_fbm_backward(L.SR_F32, B, H, W, L.view(xn), L.view(b2), L.view(b4), L.view(b8), gates.data_ptr(), L.view(da),
+            L.check(lib.sr_fbm_backward(code, B, H, W, L.view(xn), L.view(b2), L.view(b4), L.view(b8), gates.data_ptr(), L.view(da),
                                         L.view(dxd), L.view(dl2), L.view(dl4), L.view(dl8), dz.data_ptr(), st), 'sr_fbm_backward')
             # 4. the band branches back through the (self-adjoint) low-pass: plane k of lowpass(dl_k)
             ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
@@ -248,7 +274,7 @@ class _FDConvFn(torch.autograd.Function):
                 out = torch.empty_like(xn)
                 planes = [scratch[0], scratch[1]]
                 planes.insert(k, out)
-                L.check(lib.sr_fbm_lowpass(plan, L.SR_F32, B, L.view(src), 0, L.view(planes[0]), L.view(planes[1]), L.view(planes[2]),
+                L.check(lib.sr_fbm_lowpass(plan, code, B, L.view(src), 0, L.view(planes[0]), L.view(planes[1]), L.view(planes[2]),
                                            None, 0, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass (adjoint)')
                 adj.append(out)
             # 5. the small weight path on torch autograd: dW_b -> parameters and pooled means
@@ -265,7 +291,7 @@ class _FDConvFn(torch.autograd.Function):
             dgw = torch.empty(3, cin, 9, dtype=torch.float32, device=dev)
             dgb = torch.empty(3, dtype=torch.float32, device=dev)
             dxn = torch.empty_like(xn)
-            L.check(lib.sr_fbm_gates_backward(L.SR_F32, B, H, W, L.view(xn), dz.data_ptr(), C.byref(lp), L.view(dxd), L.view(adj[0]),
+            L.check(lib.sr_fbm_gates_backward(code, B, H, W, L.view(xn), dz.data_ptr(), C.byref(lp), L.view(dxd), L.view(adj[0]),
                                               L.view(adj[1]), L.view(adj[2]), dpooled.data_ptr(), cin, L.view(dxn), dgw.data_ptr(),
                                               dgb.data_ptr(), st), 'sr_fbm_gates_backward')
             for k in range(3):
@@ -287,6 +313,10 @@ def conv_train(m, x):
 def rrdbnet_train_forward(net, x):
     """RRDBNet.forward (basicsr rrdbnet_arch.py; call site train/train_realESRGAN_fdconv_1.py:114) with an autograd graph."""
     _check_input(x, 'RRDBNet (train)')
+    io_dt = x.dtype
+    if net.compute_dtype is not None and net.compute_dtype != io_dt:  # e.g. float32 data, bf16 compute (mixed precision)
+        x = x.to(net.compute_dtype)
+        _check_input(x, 'RRDBNet (train)')
     lrelu = lambda t: F.leaky_relu(t, 0.2)
     if net.scale == 2:
         x = F.pixel_unshuffle(x, 2)
@@ -308,7 +338,7 @@ def rrdbnet_train_forward(net, x):
     feat = feat + conv_train(net.conv_body, body)
     feat = lrelu(conv_train(net.conv_up1, F.interpolate(feat, scale_factor=2, mode='nearest')))
     feat = lrelu(conv_train(net.conv_up2, F.interpolate(feat, scale_factor=2, mode='nearest')))
-    return conv_train(net.conv_last, lrelu(conv_train(net.conv_hr, feat)))
+    return conv_train(net.conv_last, lrelu(conv_train(net.conv_hr, feat))).to(io_dt)
 
 
 # ------------------------------------------------------------------------------------------------------------------

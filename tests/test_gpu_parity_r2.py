@@ -316,8 +316,10 @@ def test_train_mode_forward_records_an_autograd_graph(sra):
     net = sra.RRDBNet(3, 3, 4, 8, 1, 4).cuda()  # modules are born in train() mode
     y = net(torch.zeros(1, 3, 8, 8, device='cuda'))
     assert y.grad_fn is not None and y.shape == (1, 3, 32, 32)
-    with pytest.raises(TypeError):  # the differentiable path computes in float32
-        net(torch.zeros(1, 3, 8, 8, device='cuda', dtype=torch.bfloat16))
+    yb = net(torch.zeros(1, 3, 8, 8, device='cuda', dtype=torch.bfloat16))  # mixed precision: bf16 activations
+    assert yb.grad_fn is not None and yb.dtype == torch.bfloat16
+    with pytest.raises(TypeError):
+        net(torch.zeros(1, 3, 8, 8, device='cuda', dtype=torch.float16))
     net.eval()
     with torch.no_grad():
         assert net(torch.zeros(1, 3, 8, 8, device='cuda')).grad_fn is None  # executor path

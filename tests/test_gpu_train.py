@@ -251,3 +251,44 @@ def test_training_reduces_the_loss_and_scale2_runs(sra):
     assert y.shape == (2, 3, 24, 24)
     y.mean().backward()
     assert net2.conv_first.weight.grad is not None and net2.conv_first.weight.grad.shape == (16, 12, 3, 3)
+
+
+def test_mixed_precision_training_step_tracks_the_float32_step(sra):
+    """bf16 compute (net.compute_dtype): MFMA convolution forward / operand gradient with split weights, MFMA low-pass, bf16
+    activations and activation gradients; parameters and weight gradients float32.  No reference counterpart (the owner
+    scripts train in float32): the yardstick is this repository's float32 path, whose gradients are pinned to the
+    reference's.  Checked: prediction PSNR, loss, and the direction of every large parameter gradient."""
+    sd = t(gp.rrdbnet_state(1, 1, 64, 1, 32, seed=7))
+    B, hw = 4, 32
+    sc = torch.linspace(0.1, 2.0, B).view(B, 1, 1, 1)
+    wf = (torch.from_numpy(gp.image_input((B, 1, hw, hw), seed=402)) * sc + (sc - 1) * 0.3).cuda()
+    srt = torch.from_numpy(gp.image_input((B, 1, 4 * hw, 4 * hw), seed=403)).cuda()
+    res = {}
+    for name, cdt in (('f32', None), ('bf16', torch.bfloat16)):
+        net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 1, 32))
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        net.compute_dtype = cdt
+        pred = net(wf)
+        assert pred.dtype == torch.float32
+        loss = sra.head.resize_l1_loss(pred, srt)
+        loss.backward()
+        res[name] = (pred.detach(), loss.item(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    p32, l32, g32 = res['f32']
+    pb, lb, gb = res['bf16']
+    span = (p32.max() - p32.min()).item()
+    mse = ((pb - p32) ** 2).mean().item()
+    psnr = 10 * np.log10(span * span / mse)
+    total32 = torch.cat([g.reshape(-1) for g in g32.values()]).double()
+    totalb = torch.cat([gb[k].reshape(-1) for k in g32]).double()
+    cos_all = float((total32 * totalb).sum() / (total32.norm() * totalb.norm()))
+    worst = 1.0
+    for k, g in g32.items():
+        if g.norm().item() < 1e-3 * total32.norm().item():
+            continue  # tiny gradients: direction dominated by rounding
+        c = float((g.double() * gb[k].double()).sum() / (g.double().norm() * gb[k].double().norm() + 1e-30))
+        worst = min(worst, c)
+    print('mixed precision vs float32 step: prediction PSNR %.1f dB, loss %.5f vs %.5f, gradient cosine %.5f overall, %.4f worst '
+          'large parameter' % (psnr, lb, l32, cos_all, worst))
+    assert psnr > 40.0 and abs(lb - l32) < 2e-3 * max(1.0, abs(l32))
+    assert cos_all > 0.995 and worst > 0.95  # measured 0.99982 / 0.966
