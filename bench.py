@@ -237,18 +237,35 @@ def run_tiled(args, world, rank, dev, dist):
     wins = r.tile_windows()
     mine = r.shard_of(wins, rank, world)
     lr_px_rank = float(sum((wins[i][0][1] - wins[i][0][0]) * (wins[i][0][3] - wins[i][0][2]) for i in mine))
+    # network time inside the timed region: events around every forward of this rank (on torch's current stream, the one
+    # the executor launches on); the rest of the step -- crops, paste, gather to rank 0, post_process -- is what does not
+    # shrink with the number of ranks
+    fwd_events = []
+    inner_forward = net.forward
+
+    def timed_forward(xin):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = inner_forward(xin)
+        e1.record()
+        fwd_events.append((e0, e1))
+        return y
+
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             r.tile_process()
             r.post_process()
         sync()
         net.profile(2)
+        net.forward = timed_forward
         t0 = time.perf_counter()
         for _ in range(args.steps):
             r.tile_process()
             out = r.post_process()
         sync()
         elapsed = time.perf_counter() - t0
+        net.forward = inner_forward
+        net_s = sum(a.elapsed_time(b) for a, b in fwd_events) / 1e3 / args.steps
         prof = net.profile_read()
         net.profile(1)
         r.tile_process()
@@ -282,9 +299,10 @@ def run_tiled(args, world, rank, dev, dist):
                    'timed_region': 'tile_process() + post_process() with the padded image resident in HBM; max over ranks incl. the gather',
                    'enhance_host_to_host_s': t_enh, 'enhance_host_to_host_out_mpix_s': out_mpix / t_enh,
                    'pre_process_s': t_pre,
-                   'non_parallel_share': {'note': 'rank 0, fraction of the timed step that is not network kernels of its own tiles '
-                                                  '(paste, gather, host launches not overlapped)',
-                                          'value': max(0.0, 1.0 - kernel_ms / 1e3 / step_s) if world == 1 else None,
+                   'non_parallel_share': {'note': 'rank 0: fraction of the timed step outside the network forwards of its own tiles '
+                                                  '(crops, paste, gather of the cores, post_process): the part that does not '
+                                                  'shrink with the number of ranks',
+                                          'value': max(0.0, 1.0 - net_s / step_s), 'network_s': net_s,
                                           'enhance_minus_timed_s': t_enh - step_s},
                    'output_ok': bool(out is None or torch.isfinite(out.float()).all()) and (full is None or full.shape == (4 * side, 4 * side, 3))},
         'roofline': roofline_fields(prof, prof_all, args.steps, lr_px_rank, 3),

@@ -107,6 +107,8 @@ _SIGS = {
     'sr_debug_force_generic_gates': (None, [C.c_int]),
     'sr_debug_split_weights': (None, [C.c_int]),
     'sr_debug_split_two_pass': (None, [C.c_int]),
+    'sr_debug_graph_replays': (C.c_long, [C.c_void_p]),
+    'sr_debug_enable_graphs': (None, [C.c_int]),
 }
 
 # every symbol include/sr_amd.h declares (the debug hook is not part of the header)

@@ -339,3 +339,41 @@ def test_dni_and_checkpoint_containers(sra, tmp_path):
     x = torch.from_numpy(gp.image_input((1, 3, 12, 10), 98))
     with torch.no_grad():
         assert (r.model(x.cuda()).cpu() - rrdbnet_forward(mixed, x)).abs().max().item() < 1e-5
+
+
+def test_small_inputs_replay_a_captured_graph_bit_for_bit(sra):
+    """Opt-in graph replay (SR_AMD_GRAPH=1; off by default because it does not pay on this stack).
+    Launch-bound inputs (B*H*W < 512^2): the executor captures everything between the input pack and the output unpack
+    on its second call with a shape and replays the graph afterwards.  Replayed forwards must equal eager ones bit for bit,
+    on changing inputs, and reloading parameters must drop the captured graphs (they carry parameter pointers)."""
+    from super_resolution_amd import _lib
+    sd = t(gp.rrdbnet_state(1, 1, 64, 1, 32, seed=7))
+    _lib.lib().sr_debug_enable_graphs(1)
+    try:
+        _graph_replay_checks(sra, _lib, sd)
+    finally:
+        _lib.lib().sr_debug_enable_graphs(0)
+
+
+def _graph_replay_checks(sra, _lib, sd):
+    for dt in (torch.float32, torch.bfloat16):
+        net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 1, 32))
+        net.load_state_dict(sd, strict=True)
+        net = net.eval().cuda()
+        xs = [torch.from_numpy(gp.image_input((2, 1, 24, 40), seed=90 + i)).cuda().to(dt) for i in range(4)]
+        with torch.no_grad():
+            got = [net(x).clone() for x in xs]          # eager, capture + replay, replay, replay
+            replays = _lib.lib().sr_debug_graph_replays(net._sr.h)
+            net.profile(True)                            # event profiling keeps the executor eager
+            ref = [net(x).clone() for x in xs]
+            net.profile(False)
+        assert replays == 3, replays
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        # new parameter values through the same pointers are picked up by the replay; a reload rebuilds the executor
+        with torch.no_grad():
+            net.conv_body.bias.add_(0.5)
+            y1 = net(xs[0])
+            assert not torch.equal(y1, got[0])
+            net.load_state_dict(sd, strict=True)
+            assert torch.equal(net(xs[0]), got[0])
