@@ -451,7 +451,7 @@ def main():
     ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--tile-pad', type=int, default=10)
-    ap.add_argument('--tile-batch', type=int, default=8)
+    ap.add_argument('--tile-batch', type=int, default=18, help='tiled: tiles of equal window size per forward (8 -> 18: 45.7 -> 49.2 out-Mpix/s at N = 1)')
     ap.add_argument('--cpu-sample', type=int, default=208, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
     ap.add_argument('--no-split-weights', action='store_true', help='A/B: plain bf16 dynamic weights instead of hi + lo pairs')
