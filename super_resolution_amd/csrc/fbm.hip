@@ -91,6 +91,13 @@ struct Radix {
     int nf;
     int r[24];
 };
+struct ColCuts {  // fbm_cols: output cut of the forward transform, operand cuts of the inverse ones [mask k][variant]
+    int u;
+    int t[9];
+};
+struct RowCuts {  // fbm_rows_inv: operand cut per band
+    int t[3];
+};
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -148,17 +155,27 @@ __device__ __forceinline__ void fft_pass_pp(const float2* __restrict__ src, floa
 // (signs for the forward transform): (R - 1) / 2 real-coefficient terms for two outputs instead of R complex terms for
 // one -- a quarter of the multiplications and half of the LDS reads of fft_pass_pp, with (R + 1) / 2 work items per
 // butterfly (1080 for a 2088-point signal, where whole butterflies would leave 72).
+// Pruning (the masks keep at most half of a spectrum): as the LAST pass of a forward transform (Ns = N / R) output u covers
+// result indices [u N/R, (u + 1) N/R), and output pairs u >= ucut lie wholly on frequencies no mask keeps: they are neither
+// computed nor stored.  As the FIRST pass of an inverse transform (Ns = 1) operand t covers source indices
+// [t N/R, (t + 1) N/R), and the pairs t >= tcut are zero in that band: they are not read.  The host computes both cuts
+// (sr_fbm_plan_create) such that tcut <= ucut on one axis, so no inverse pass reads what the forward pass left unwritten.
+// 0 = no pruning.
 template <bool INV>
 __device__ __forceinline__ void fft_pass_prime(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
-                                               int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+                                               int P, const float2* __restrict__ tw, const float* __restrict__ premul, int tcut,
+                                               int ucut) {
     const int NR = N / R;
     const int tstep = NR / Ns;
     const int half = (R + 1) / 2;  // outputs u = 0 .. half-1 (u = 0 pairs with itself)
-    for (int it = threadIdx.x; it < NR * half * P; it += blockDim.x) {
+    const int nt = tcut > 0 && tcut < half ? tcut : half;
+    const int nu = ucut > 0 && ucut < half ? ucut : half;
+    const bool notw = Ns == 1;  // first pass: every pass twiddle is 1
+    for (int it = threadIdx.x; it < NR * nu * P; it += blockDim.x) {
         const int p = it % P;
         const int o = it / P;
-        const int u = o % half;
-        const int j = o / half;
+        const int u = o % nu;
+        const int j = o / nu;
         const int jhi = j / Ns, k = j - jhi * Ns;
         const int ks = k * tstep;  // pass twiddle of operand t: tw[t * ks], t * ks < N
         float2 z0 = src[j * P + p];
@@ -169,16 +186,9 @@ __device__ __forceinline__ void fft_pass_prime(const float2* __restrict__ src, f
         float2 a = z0, bsum = make_float2(0.f, 0.f);
         int m = 0;      // (u * t) mod R
         int q1 = 0, q2 = R * ks;  // t * ks and (R - t) * ks
-        for (int t = 1; t < half; ++t) {
+        for (int t = 1; t < nt; ++t) {
             m += u;
             if (m >= R) m -= R;
-            q1 += ks;
-            q2 -= ks;
-            float2 w1 = tw[q1], w2 = tw[q2 >= N ? q2 - N : q2];
-            if (INV) {
-                w1.y = -w1.y;
-                w2.y = -w2.y;
-            }
             const int s1 = j + t * NR, s2 = j + (R - t) * NR;
             float2 x1 = src[s1 * P + p], x2 = src[s2 * P + p];
             if (premul) {
@@ -188,7 +198,18 @@ __device__ __forceinline__ void fft_pass_prime(const float2* __restrict__ src, f
                 x2.x *= m2;
                 x2.y *= m2;
             }
-            const float2 z1 = cmul(x1, w1), z2 = cmul(x2, w2);
+            float2 z1 = x1, z2 = x2;
+            if (!notw) {  // block-uniform
+                q1 += ks;
+                q2 -= ks;
+                float2 w1 = tw[q1], w2 = tw[q2 >= N ? q2 - N : q2];
+                if (INV) {
+                    w1.y = -w1.y;
+                    w2.y = -w2.y;
+                }
+                z1 = cmul(x1, w1);
+                z2 = cmul(x2, w2);
+            }
             const float2 cs = tw[m * NR];  // (cos, -sin) of 2 pi u t / R
             a.x += (z1.x + z2.x) * cs.x;
             a.y += (z1.y + z2.y) * cs.x;
@@ -291,7 +312,8 @@ __device__ __forceinline__ void fft_pass_bfly(const float2* __restrict__ src, fl
 
 template <bool INV, int PP>
 __device__ __forceinline__ void fft_pass_r(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
-                                           int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+                                           int P, const float2* __restrict__ tw, const float* __restrict__ premul, int tcut,
+                                           int ucut) {
     switch (R) {  // block-uniform
         case 2: fft_pass_bfly<INV, PP, 2>(src, dst, N, Ns, P, tw, premul); break;
         case 3: fft_pass_bfly<INV, PP, 3>(src, dst, N, Ns, P, tw, premul); break;
@@ -299,33 +321,37 @@ __device__ __forceinline__ void fft_pass_r(const float2* __restrict__ src, float
         case 5: fft_pass_bfly<INV, PP, 5>(src, dst, N, Ns, P, tw, premul); break;
         case 7: fft_pass_bfly<INV, (PP < 2 ? PP : 2), 7>(src, dst, N, Ns, P, tw, premul); break;  // 7 x PP operands in registers
         default:
-            if (R & 1) fft_pass_prime<INV>(src, dst, N, R, Ns, P, tw, premul);  // odd primes: conjugate output pairs
+            if (R & 1) fft_pass_prime<INV>(src, dst, N, R, Ns, P, tw, premul, tcut, ucut);  // odd primes: conjugate output pairs
             else fft_pass_pp<INV, PP>(src, dst, N, R, Ns, P, tw, premul);
     }
 }
 
 template <bool INV>
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int N, int R, int Ns,
-                                         int P, const float2* __restrict__ tw, const float* __restrict__ premul) {
+                                         int P, const float2* __restrict__ tw, const float* __restrict__ premul, int tcut,
+                                         int ucut) {
     // signals per work item: as many as leave at least one butterfly for every thread of the block
     const int bf = N / R, nt = blockDim.x;
-    if ((P & 3) == 0 && bf * (P >> 2) >= nt) fft_pass_r<INV, 4>(src, dst, N, R, Ns, P, tw, premul);
-    else if ((P & 1) == 0 && bf * (P >> 1) >= nt) fft_pass_r<INV, 2>(src, dst, N, R, Ns, P, tw, premul);
-    else fft_pass_r<INV, 1>(src, dst, N, R, Ns, P, tw, premul);
+    if ((P & 3) == 0 && bf * (P >> 2) >= nt) fft_pass_r<INV, 4>(src, dst, N, R, Ns, P, tw, premul, tcut, ucut);
+    else if ((P & 1) == 0 && bf * (P >> 1) >= nt) fft_pass_r<INV, 2>(src, dst, N, R, Ns, P, tw, premul, tcut, ucut);
+    else fft_pass_r<INV, 1>(src, dst, N, R, Ns, P, tw, premul, tcut, ucut);
 }
 
 // Runs all passes; returns the buffer that holds the result.  bufA holds the input.  When
 // `keep_input` is set the input buffer is never written (needs a third buffer bufC).
 // (forced inline: as an out-of-line function -- which hipcc chose once the pass switch grew by four more radices -- the
 // kernels took a stack, passed the Radix kernel argument by reference and faulted in the 33-point test)
+// `cut`: pruning of the prime pass (fft_pass_prime) -- the output cut of the last pass of a forward transform, the operand
+// cut of the first pass of an inverse transform; 0 = none.
 template <bool INV>
 __device__ __forceinline__ float2* fft_run(float2* bufA, float2* bufB, float2* bufC, bool keep_input, int N, const Radix& rx, int P,
-                           const float2* tw, const float* premul) {
+                           const float2* tw, const float* premul, int cut) {
     float2* src = bufA;
     float2* dst = bufB;
     int Ns = 1;
     for (int f = 0; f < rx.nf; ++f) {
-        fft_pass<INV>(src, dst, N, rx.r[f], Ns, P, tw, f == 0 ? premul : nullptr);
+        fft_pass<INV>(src, dst, N, rx.r[f], Ns, P, tw, f == 0 ? premul : nullptr, (INV && f == 0) ? cut : 0,
+                      (!INV && f == rx.nf - 1) ? cut : 0);
         __syncthreads();
         Ns *= rx.r[f];
         float2* nxt = (src == bufA && keep_input) ? bufC : src;
@@ -360,7 +386,7 @@ struct PairIO<bf16_t> {
 template <typename T>
 __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, int H, int W, int C, int PT, int P, Radix rx,
                                                     const float2* __restrict__ tw, const int* __restrict__ cols, int n2,
-                                                    float2* __restrict__ t1) {
+                                                    float2* __restrict__ t1, int ucut) {
     const int lp = 31 - __clz(P);  // P is a power of two (pairs_per_group)
     float2* bufA = (float2*)smem;
     float2* bufB = bufA + W * P;
@@ -384,7 +410,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, 
         bufA[it] = v;
     }
     __syncthreads();
-    const float2* res = fft_run<false>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
+    const float2* res = fft_run<false>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr, ucut);
     // t1[b][idx][h][PT]
     #pragma unroll 8
     for (int it = threadIdx.x; it < n2 * P; it += blockDim.x) {
@@ -394,7 +420,8 @@ __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, 
 }
 
 // ---- kernel 2: FFT along H, row masks, inverse FFT along H ----------------------------------
-__global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Radix rx, const float2* __restrict__ tw,
+__global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Radix rx, Radix rxi, ColCuts cuts,
+                                                const float2* __restrict__ tw,
                                                 const int* __restrict__ colinfo, int n2, int n4, int n8,
                                                 const float* __restrict__ rowmask, const float2* __restrict__ t1,
                                                 float2* __restrict__ y2, float2* __restrict__ y4,
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
         buf0[it] = (p0 + p < PT) ? col[(long)h * PT + p0 + p] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    float2* S = fft_run<false>(buf0, buf1, nullptr, false, H, rx, P, twl, nullptr);
+    float2* S = fft_run<false>(buf0, buf1, nullptr, false, H, rx, P, twl, nullptr, cuts.u);
     float2* other = (S == buf0) ? buf1 : buf0;
     const int variant = colinfo[idx * 4 + 0];
     if (pooled && idx == 0 && threadIdx.x < P) {  // column 0 comes first: S[0] = plane sums of the pair
@@ -430,7 +457,10 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
     for (int k = 0; k < 3; ++k) {
         if (kidx[k] < 0) continue;  // block-uniform
         const float* rm = rowmask + (k * 3 + variant) * H;
-        const float2* res = fft_run<true>(S, buf2, other, true, H, rx, P, twl, rm);
+        const int tc = k == 0 ? (variant == 0 ? cuts.t[0] : (variant == 1 ? cuts.t[1] : cuts.t[2]))
+                              : (k == 1 ? (variant == 0 ? cuts.t[3] : (variant == 1 ? cuts.t[4] : cuts.t[5]))
+                                        : (variant == 0 ? cuts.t[6] : (variant == 1 ? cuts.t[7] : cuts.t[8])));
+        const float2* res = fft_run<true>(S, buf2, other, true, H, rxi, P, twl, rm, tc);
         float2* y = ys[k];
         #pragma unroll 8
         for (int it = threadIdx.x; it < H * P; it += blockDim.x) {
@@ -444,7 +474,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
 // ---- kernel 3: inverse FFT along W, write the three low-pass tensors ------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, int pair, int H, int W, int C, int PT, int P,
-                                                    Radix rx, const float2* __restrict__ tw,
+                                                    Radix rx, RowCuts cuts, const float2* __restrict__ tw,
                                                     const int* __restrict__ cols2, const int* __restrict__ cols4,
                                                     const int* __restrict__ cols8, int n2, int n4, int n8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
@@ -472,7 +502,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
             if (p0 + p < PT) bufA[ck[k][i] * P + p] = yr[(long)i * PT + p0 + p];
         }
         __syncthreads();
-        const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr);
+        const float2* res = fft_run<true>(bufA, bufB, nullptr, false, W, rx, P, twl, nullptr, k == 0 ? cuts.t[0] : (k == 1 ? cuts.t[1] : cuts.t[2]));
         #pragma unroll 8
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) {
             const int p = it & (P - 1), w = it >> lp;
@@ -505,6 +535,12 @@ static Radix make_radix(const int* r, int nf) {
     for (int i = 0; i < nf; ++i) x.r[i] = r[i];
     return x;
 }
+static Radix reversed(const Radix& a) {
+    Radix x{};
+    x.nf = a.nf;
+    for (int i = 0; i < a.nf; ++i) x.r[i] = a.r[a.nf - 1 - i];
+    return x;
+}
 
 int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8,
                        float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -525,6 +561,12 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     float2* y4 = y2 + (size_t)B * H * n2 * PT;
     float2* y8 = y4 + (size_t)B * H * n4 * PT;
     const Radix rw = make_radix(pl->radW, pl->nfW), rh = make_radix(pl->radH, pl->nfH);
+    const Radix rwi = reversed(rw), rhi = reversed(rh);  // inverse transforms run the largest radix first (pruned operands)
+    ColCuts cc;
+    cc.u = pl->ucutH;
+    for (int i = 0; i < 9; ++i) cc.t[i] = pl->tcutH[i];
+    RowCuts rc3;
+    for (int i = 0; i < 3; ++i) rc3.t[i] = pl->tcutW[i];
     const int Pw = pl->Pw, Ph = pl->Ph;
     const size_t lds_w = (2ul * W * Pw + W) * sizeof(float2), lds_h = (3ul * H * Ph + H) * sizeof(float2);  // buffers + twiddles
     dim3 g1(B * H, cdiv(PT, Pw)), g2(B * n2, cdiv(PT, Ph));
@@ -547,18 +589,18 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     }
     SR_LDS_ATTR(lds_h, fbm_cols);
     if (dtype == SR_F32)
-        fbm_rows_fwd<float><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+        fbm_rows_fwd<float><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1, pl->ucutW);
     else
-        fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1);
+        fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1, pl->ucutW);
     SR_LAUNCH_CHECK();
-    fbm_cols<<<g2, th_, lds_h, st>>>(H, W, PT, Ph, rh, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
+    fbm_cols<<<g2, th_, lds_h, st>>>(H, W, PT, Ph, rh, rhi, cc, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
                                      pooled, pooled_ld, C);
     SR_LAUNCH_CHECK();
     if (dtype == SR_F32)
-        fbm_rows_inv<float><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+        fbm_rows_inv<float><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rwi, rc3, pl->tw_w, pl->cols, pl->cols4,
                                                     pl->cols8, n2, n4, n8, y2, y4, y8);
     else
-        fbm_rows_inv<bf16_t><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, pl->cols4,
+        fbm_rows_inv<bf16_t><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rwi, rc3, pl->tw_w, pl->cols, pl->cols4,
                                                      pl->cols8, n2, n4, n8, y2, y4, y8);
     SR_LAUNCH_CHECK();
     return SR_OK;
@@ -641,6 +683,49 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
             rmask[(k * 3 + 1) * H + r] = bneg;
             rmask[(k * 3 + 2) * H + r] = 0.5f * (a + bneg);
         }
+    {   // generic FFT: cuts of the prime pass (fft_pass_prime).  used[i] != 0: index i of the spectrum carries weight.
+        auto pair_cut = [](const std::vector<char>& used, int N, int R) {
+            // 1 + the last conjugate pair (t, R - t), t < (R + 1) / 2, of N/R-index ranges that holds a used index
+            const int nr = N / R, half = (R + 1) / 2;
+            auto range_used = [&](int t) {
+                for (int i = t * nr; i < (t + 1) * nr; ++i)
+                    if (used[i]) return true;
+                return false;
+            };
+            int cut = 1;
+            for (int t = 1; t < half; ++t)
+                if (range_used(t) || range_used(R - t)) cut = t + 1;
+            return cut;
+        };
+        auto prime_radix = [](const int* rad, int nf) {
+            const int R = nf > 0 ? rad[nf - 1] : 0;
+            return (R > 7 && (R & 1)) ? R : 0;
+        };
+        const int Rw = prime_radix(pl->radW, pl->nfW), Rh = prime_radix(pl->radH, pl->nfH);
+        pl->ucutW = pl->ucutH = 0;
+        for (int i = 0; i < 3; ++i) pl->tcutW[i] = 0;
+        for (int i = 0; i < 9; ++i) pl->tcutH[i] = 0;
+        if (Rw) {
+            for (int k = 0; k < 3; ++k) {
+                std::vector<char> used(W, 0);
+                for (int c : lists[k]) used[c] = 1;
+                pl->tcutW[k] = pair_cut(used, W, Rw);
+                if (k == 0) pl->ucutW = pl->tcutW[0];  // rows_fwd stores the columns of the widest mask
+            }
+        }
+        if (Rh) {
+            std::vector<char> any(H, 0);
+            for (int kv = 0; kv < 9; ++kv) {
+                std::vector<char> used(H, 0);
+                for (int r = 0; r < H; ++r) {
+                    used[r] = rmask[(size_t)kv * H + r] != 0.f;
+                    any[r] |= used[r];
+                }
+                pl->tcutH[kv] = pair_cut(used, H, Rh);
+            }
+            pl->ucutH = pair_cut(any, H, Rh);  // >= every tcutH: the inverse passes read only what the forward pass wrote
+        }
+    }
     {   // first-pass operand ranges of the pruned inverse column transform (same radix choice as fbm_fast.hip)
         const int r0 = (H % 8 == 0 && H != 16) ? 8 : (H % 4 == 0 ? 4 : 2), nr0 = H / r0;
         for (int kv = 0; kv < 9; ++kv) {

@@ -18,6 +18,11 @@ struct sr_fbm_plan {
     void* dev_block;       // one allocation backing all of the above
     int half[3];           // kept columns of mask k are [0,half) u (W-half, W) when contiguous != 0
     int contiguous;
+    // generic FFT, largest radix R an odd prime > 7 (it runs last in forward, first in inverse transforms): conjugate
+    // pairs (u, R - u) of its outputs / operands at or beyond these indices are never used / all zero (fbm.hip)
+    int ucutW, ucutH;      // forward along W / H: output pairs u >= ucut fall on columns / rows no mask keeps
+    int tcutW[3];          // inverse along W, band k: operand pairs t >= tcut hold no kept column
+    int tcutH[9];          // inverse along H, [mask k][variant]: operand pairs t >= tcut have zero row-mask weights
     int row_zmask[9];      // [mask k][variant]: bit t set = rows [t*H/R0, (t+1)*H/R0) of that row mask are all zero (R0 = first radix of H)
     // ---- real-basis tables of the MFMA path (fbm_mfma.hip); mf_ok == 0 when the shape / masks are not covered ----
     int mf_ok;

@@ -134,7 +134,10 @@ def _run_lowpass(L, lib, x, dt, ups):
 @pytest.mark.parametrize('shape', [(2, 6, 12, 12), (1, 5, 33, 35), (2, 32, 40, 48), (1, 64, 64, 64), (1, 8, 130, 77),
                                    (1, 4, 58, 36), (1, 2, 128, 256),
                                    # long non-power-of-two sides: 512- and 1024-thread blocks, radix 3 / 5 / 7 butterflies
-                                   (1, 3, 1200, 36), (1, 4, 24, 1920), (1, 2, 2100, 20)])
+                                   (1, 3, 1200, 36), (1, 4, 24, 1920), (1, 2, 2100, 20),
+                                   # largest radix an odd prime > 7 on both axes: pruned prime passes (forward output
+                                   # cut, inverse operand cut), even and odd lengths
+                                   (1, 2, 46, 62), (2, 4, 34, 38), (1, 3, 51, 39), (1, 2, 174, 190), (1, 2, 11, 13)])
 def test_fbm_lowpass_fp32(L, shape):
     x = torch.from_numpy(gp.signed_input(shape, 11))
     bands, pooled = run_lowpass(L, x, torch.float32)
