@@ -109,6 +109,7 @@ _SIGS = {
     'sr_debug_split_two_pass': (None, [C.c_int]),
     'sr_debug_graph_replays': (C.c_long, [C.c_void_p]),
     'sr_debug_enable_graphs': (None, [C.c_int]),
+    'sr_debug_wgrad_valu': (None, [C.c_int]),
 }
 
 # every symbol include/sr_amd.h declares (the debug hook is not part of the header)

@@ -140,39 +140,6 @@ constexpr int NPIX = PH * PW;                // 612 rows of 64 B
 // lanes of every ds_read_b128 lane group (rows distinct mod 16) land on 16 distinct slots.
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-}
-__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-
-// g1*x + (g2-g1)*L2 + (g3-g2)*L4 + (1-g3)*L8 on 8 bf16 channels: channel pairs as float2, one v_pk_mul_f32 + three
-// v_pk_fma_f32 per pair (written as four products and three adds the compiler used ten instructions per pair)
-typedef float float2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2v unpack2(uint32_t u) {
-    float2v r;
-    r.x = lo_f(u);
-    r.y = hi_f(u);
-    return r;
-}
-__device__ __forceinline__ uint32_t modulate2(uint32_t x, uint32_t a, uint32_t b, uint32_t c, float2v c0, float2v c1, float2v c2,
-                                              float2v c3) {
-    float2v r = c0 * unpack2(x);
-    r = __builtin_elementwise_fma(c1, unpack2(a), r);
-    r = __builtin_elementwise_fma(c2, unpack2(b), r);
-    r = __builtin_elementwise_fma(c3, unpack2(c), r);
-    return pack2(r.x, r.y);
-}
-__device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, float c0, float c1, float c2, float c3) {
-    const float2v k0 = {c0, c0}, k1 = {c1, c1}, k2 = {c2, c2}, k3 = {c3, c3};
-    uint4 r;
-    r.x = modulate2(x.x, a.x, b.x, c.x, k0, k1, k2, k3);
-    r.y = modulate2(x.y, a.y, b.y, c.y, k0, k1, k2, k3);
-    r.z = modulate2(x.z, a.z, b.z, c.z, k0, k1, k2, k3);
-    r.w = modulate2(x.w, a.w, b.w, c.w, k0, k1, k2, k3);
-    return r;
-}
-
 // MT = number of 32-wide output-channel tiles handled by the workgroup (1 or 2).
 //
 // Producer / consumer workgroup of 8 waves, one per CU, two LDS stages:

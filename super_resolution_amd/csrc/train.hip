@@ -115,6 +115,208 @@ __global__ __launch_bounds__(256) void wgrad_kernel(Concat in, int H, int W, con
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient on the matrix cores (bf16 tensors, Cout = 32 or 64, 32-channel input chunks inside one segment).
+// dW[t][o][i] = sum_p dy[p][o] a[p + off(t)][i] is a GEMM whose contraction runs over PIXELS, while both tensors keep
+// channels innermost: the dy strip and the haloed operand strip are staged pixel-major in LDS exactly as they lie in
+// memory (16-byte stores, the operand band-mixed on the way as in the forward loader) and ds_read_b64_tr_b16 hands every
+// lane the 8 pixel values of its channel -- the MFMA fragment layout of BOTH operands, no software transpose.  A tap is
+// a pixel offset of the operand fragment's base address.
+//   workgroup : sample b, 32-channel chunk i0, a run of 4 x 32-pixel strips (8 k-steps of 16 pixels each)
+//   wave      : Cout = 32: strip row = wave, all 9 taps (9 accumulator tiles);
+//               Cout = 64: output-channel half = wave & 1, strip rows (wave >> 1) and (wave >> 1) + 2
+//   epilogue  : the waves' partial tiles are summed through LDS and added to dW with one float atomic per element.
+constexpr int WM_RS = 4, WM_WC = 32, WM_AW = WM_WC + 2;
+constexpr int WM_A_BYTES = (WM_RS + 2) * WM_AW * 64;  // haloed operand strip, 64 B (32 channels) per pixel
+constexpr int WM_D_BYTES = WM_RS * WM_WC * 64;        // dy strip per 32-channel half
+constexpr int WM_RED_BYTES = 9 * 16 * 64 * 4;         // one wave's accumulators
+typedef __attribute__((ext_vector_type(8))) short wm_short8;
+typedef __attribute__((ext_vector_type(16))) float wm_float16;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short wm_s4;
+
+// fragment (32 channels x 16 pixels from pixel `pix0` of a 64-byte-per-pixel image): lane l gets channel l % 32, pixels
+// 8 (l / 32) .. + 7.  Lane 4q + p of a 16-lane group supplies pixel row q, channels 4p .. 4p + 3 of the group's 16.
+__device__ __forceinline__ wm_short8 wm_frag(const char* img, int pix0, int lane) {
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int off = (pix0 + 8 * (g4 >> 1) + q) * 64 + 32 * (g4 & 1) + 8 * p;
+    const wm_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wm_s4*)(img + off));
+    const wm_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wm_s4*)(img + off + 4 * 64));
+    wm_short8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+extern __shared__ __attribute__((aligned(16))) char wm_smem[];
+
+struct WmSeg {  // the segment that holds this launch's channel chunks (plain NHWC views, 16-byte aligned)
+    const bf16_t *x, *l2, *l4, *l8;
+    long x_bs, b_bs;   // sample strides (elements) of x and of the band planes
+    int x_ld, b_ld;    // pixel strides
+    int c0, nchunk;    // first concat channel of the segment, 32-channel chunks in it
+};
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WmSeg sg, int bands, int ups, int H, int W, int cin,
+                                                         const float* __restrict__ gates, const bf16_t* __restrict__ dy,
+                                                         long dy_bs, int dy_ld, float* __restrict__ dw, long dw_bstride,
+                                                         int strips_per_block) {
+    constexpr int COUT = 32 * MT;
+    char* a_sh = wm_smem;
+    char* d_sh = wm_smem + WM_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk_i = blockIdx.x;          // 32-channel chunk inside the segment
+    const int b = blockIdx.z;
+    const int sx = (W + WM_WC - 1) / WM_WC, nstrips = sx * ((H + WM_RS - 1) / WM_RS);
+    const int s_begin = blockIdx.y * strips_per_block;
+    const int s_end = min(nstrips, s_begin + strips_per_block);
+    const int Ws = W >> ups;
+    const bf16_t* xb = sg.x + (long)b * sg.x_bs + chunk_i * 32;
+    const bf16_t* l2b = bands ? sg.l2 + (long)b * sg.b_bs + chunk_i * 32 : nullptr;
+    const bf16_t* l4b = bands ? sg.l4 + (long)b * sg.b_bs + chunk_i * 32 : nullptr;
+    const bf16_t* l8b = bands ? sg.l8 + (long)b * sg.b_bs + chunk_i * 32 : nullptr;
+    const float4* gb = bands ? (const float4*)gates + (long)b * H * W : nullptr;
+    const bf16_t* dyb = dy + (long)b * dy_bs;
+    wm_float16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int mb = MT == 2 ? (wave & 1) : 0;
+    const char* d_img = d_sh + mb * WM_D_BYTES;
+    for (int st = s_begin; st < s_end; ++st) {
+        const int h0 = (st / sx) * WM_RS, w0 = (st % sx) * WM_WC;
+        __syncthreads();  // the previous strip's fragments have been read
+        // operand strip with halo: 16-byte items (pixel, 8-channel group)
+        for (int it = tid; it < (WM_RS + 2) * WM_AW * 4; it += 256) {
+            const int ch = it & 3, pi = it >> 2;
+            const int py = pi / WM_AW, px = pi - py * WM_AW;
+            const int h = h0 + py - 1, w = w0 + px - 1;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (h >= 0 && h < H && w >= 0 && w < W) {
+                const long ps = (long)(h >> ups) * Ws + (w >> ups);
+                v = *(const uint4*)(xb + ps * sg.x_ld + 8 * ch);
+                if (bands) {
+                    const long p = (long)h * W + w;
+                    const float4 g = gb[p];
+                    const uint4 v2 = *(const uint4*)(l2b + p * sg.b_ld + 8 * ch);
+                    const uint4 v4 = *(const uint4*)(l4b + p * sg.b_ld + 8 * ch);
+                    const uint4 v8 = *(const uint4*)(l8b + p * sg.b_ld + 8 * ch);
+                    v = modulate8(v, v2, v4, v8, g.x, g.y - g.x, g.z - g.y, 1.0f - g.z);
+                }
+            }
+            *(uint4*)(a_sh + pi * 64 + ch * 16) = v;
+        }
+        // dy strip: [half][pixel][32 channels]
+        for (int it = tid; it < WM_RS * WM_WC * 4 * MT; it += 256) {
+            const int c8 = it % (4 * MT), pi = it / (4 * MT);
+            const int py = pi / WM_WC, px = pi - py * WM_WC;
+            const int h = h0 + py, w = w0 + px;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (h < H && w < W) v = *(const uint4*)(dyb + ((long)h * W + w) * dy_ld + 8 * c8);
+            *(uint4*)(d_sh + (c8 >> 2) * WM_D_BYTES + pi * 64 + (c8 & 3) * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < MT; ++rr) {
+            const int py = MT == 2 ? (wave >> 1) + 2 * rr : wave;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const wm_short8 fa = wm_frag(d_img, py * WM_WC + 16 * ks, lane);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const wm_short8 fb = wm_frag(a_sh, (py + t / 3) * WM_AW + 16 * ks + t % 3, lane);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // sum the partial tiles of the waves that share an output-channel half, then one atomic per element
+    __syncthreads();
+    float* red = (float*)wm_smem + mb * (WM_RED_BYTES / 4);
+    constexpr int ROUNDS = MT == 2 ? 2 : 4;
+    const int my_round = MT == 2 ? (wave >> 1) : wave;
+#pragma unroll 1
+    for (int r0 = 0; r0 < ROUNDS; ++r0) {
+        if (my_round == r0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* q = red + (t * 16 + r) * 64 + lane;
+                    *q = r0 == 0 ? acc[t][r] : *q + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = dw + (long)b * dw_bstride;
+    const int i0 = sg.c0 + chunk_i * 32;
+    for (int e = tid; e < MT * 9 * 16 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, t = (e >> 10) % 9, m = e / (9 * 1024);
+        const int o = m * 32 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3), ci = i0 + (l & 31);
+        atomicAdd(out + ((long)t * COUT + o) * cin + ci, ((const float*)wm_smem)[e]);
+    }
+}
+
+int g_wgrad_valu = 0;  // debug hook: keep bf16 weight gradients on the VALU kernel
+
+// true when (segment s of) the operand can be staged with 16-byte loads in 32-channel chunks
+static bool wm_view_ok(const View& v) {
+    return v.p && v.csh == 3 && v.cbs == 8 && v.ld % 8 == 0 && v.c0 % 8 == 0 && v.bs % 8 == 0 && (uintptr_t)v.p % 16 == 0;
+}
+
+static int wgrad_mfma_launch(const Concat& c, int B, int H, int W, const float* gates, const View& dyv, int cout, int per_sample,
+                             float* dw, hipStream_t st) {
+    if (g_wgrad_valu || (cout != 32 && cout != 64) || !wm_view_ok(dyv) || dyv.c0 + cout > dyv.ld) return SR_NOT_ELIGIBLE;
+    for (int s = 0; s < c.nseg; ++s) {
+        const int cs = c.cstart[s + 1] - c.cstart[s];
+        if (cs % 32 || c.cstart[s] % 32 || !wm_view_ok(c.x[s])) return SR_NOT_ELIGIBLE;
+        if (c.bands && (!wm_view_ok(c.l2[s]) || !wm_view_ok(c.l4[s]) || !wm_view_ok(c.l8[s]) || c.l4[s].ld != c.l2[s].ld ||
+                        c.l8[s].ld != c.l2[s].ld || c.l4[s].bs != c.l2[s].bs || c.l8[s].bs != c.l2[s].bs))
+            return SR_NOT_ELIGIBLE;
+    }
+    const int cin = c.ctot;
+    const long wn = 9L * cout * cin;
+    const int nstrips = cdiv(W, WM_WC) * cdiv(H, WM_RS);
+    const int mt = cout / 32;
+    const size_t lds = (size_t)(WM_A_BYTES + mt * WM_D_BYTES) > (size_t)mt * WM_RED_BYTES ? (size_t)(WM_A_BYTES + mt * WM_D_BYTES)
+                                                                                         : (size_t)mt * WM_RED_BYTES;
+    // about 1024 workgroups per launch over all segments: fills the chip, few atomic rounds per element
+    int spb = (int)(((long)nstrips * (cin / 32) * B + 1023) / 1024);
+    if (spb < 1) spb = 1;
+    for (int s = 0; s < c.nseg; ++s) {
+        WmSeg sg;
+        sg.x = (const bf16_t*)c.x[s].p + c.x[s].c0;
+        sg.x_bs = c.x[s].bs;
+        sg.x_ld = c.x[s].ld;
+        sg.l2 = sg.l4 = sg.l8 = nullptr;
+        sg.b_bs = 0;
+        sg.b_ld = 0;
+        if (c.bands) {
+            sg.l2 = (const bf16_t*)c.l2[s].p + c.l2[s].c0;
+            sg.l4 = (const bf16_t*)c.l4[s].p + c.l4[s].c0;
+            sg.l8 = (const bf16_t*)c.l8[s].p + c.l8[s].c0;
+            sg.b_bs = c.l2[s].bs;
+            sg.b_ld = c.l2[s].ld;
+        }
+        sg.c0 = c.cstart[s];
+        sg.nchunk = (c.cstart[s + 1] - c.cstart[s]) / 32;
+        const dim3 grid(sg.nchunk, cdiv(nstrips, spb), B);
+        const bf16_t* dyp = (const bf16_t*)dyv.p + dyv.c0;
+        if (mt == 1) {
+            SR_LDS_ATTR(lds, wgrad_mfma_kernel<1>);
+            wgrad_mfma_kernel<1><<<grid, 256, lds, st>>>(sg, c.bands, c.ups, H, W, cin, gates, dyp, dyv.bs, dyv.ld, dw,
+                                                        per_sample ? wn : 0, spb);
+        } else {
+            SR_LDS_ATTR(lds, wgrad_mfma_kernel<2>);
+            wgrad_mfma_kernel<2><<<grid, 256, lds, st>>>(sg, c.bands, c.ups, H, W, cin, gates, dyp, dyv.bs, dyv.ld, dw,
+                                                        per_sample ? wn : 0, spb);
+        }
+        SR_LAUNCH_CHECK();
+    }
+    return SR_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_kernel(View dy, long npix, long total_pix, int cout, float* __restrict__ dbias,
                                                         int pix_per_block) {
@@ -308,6 +510,8 @@ extern "C" int sr_conv_weight_transpose(const void* w, void* wt, int dtype, int 
     return SR_OK;
 }
 
+extern "C" void sr_debug_wgrad_valu(int on) { sr::g_wgrad_valu = on; }
+
 extern "C" int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat* in, const float* gates, sr_view dy, int cout,
                                 int per_sample, float* dw, float* dbias, void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && B <= 65535 && H > 0 && W > 0 && in && cout > 0 && dw && plain_view_ok(dy, cout));
@@ -328,11 +532,15 @@ extern "C" int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat*
     if (spb < 1) spb = 1;
     dim3 grid(tiles, cdiv(nstrips, spb), B);
     const View dyv = to_view(dy, npix);
-    if (dtype == SR_F32)
-        wgrad_kernel<float><<<grid, 256, 0, st>>>(c, H, W, gates, dyv, cout, dw, per_sample ? wn : 0, spb);
-    else
-        wgrad_kernel<bf16_t><<<grid, 256, 0, st>>>(c, H, W, gates, dyv, cout, dw, per_sample ? wn : 0, spb);
-    SR_LAUNCH_CHECK();
+    rc = dtype == SR_BF16 ? wgrad_mfma_launch(c, B, H, W, gates, dyv, cout, per_sample, dw, st) : SR_NOT_ELIGIBLE;
+    if (rc != SR_OK && rc != SR_NOT_ELIGIBLE) return rc;
+    if (rc == SR_NOT_ELIGIBLE) {
+        if (dtype == SR_F32)
+            wgrad_kernel<float><<<grid, 256, 0, st>>>(c, H, W, gates, dyv, cout, dw, per_sample ? wn : 0, spb);
+        else
+            wgrad_kernel<bf16_t><<<grid, 256, 0, st>>>(c, H, W, gates, dyv, cout, dw, per_sample ? wn : 0, spb);
+        SR_LAUNCH_CHECK();
+    }
     if (dbias) {
         SR_HIP(hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), st));
         const long total = (long)B * npix;

@@ -99,6 +99,53 @@ def test_wgrad_and_transposed_conv_vs_autograd(sra, B, cin, cout, H, W, bands, p
     close(da.permute(0, 3, 1, 2), a.grad, 'da')
 
 
+@pytest.mark.parametrize('B,segs,cout,H,W,bands,ups,per_sample', [(2, (64, 32), 32, 20, 24, True, 0, True),
+                                                                  (1, (64, 32, 32, 32, 32), 64, 33, 37, True, 0, True),
+                                                                  (3, (64,), 64, 16, 40, False, 1, False),
+                                                                  (2, (32,), 32, 5, 3, False, 0, True)])
+def test_wgrad_mfma_matches_valu_kernel_bf16(sra, B, segs, cout, H, W, bands, ups, per_sample):
+    """bf16 weight gradients on the matrix cores (pixels as the contraction axis, transposed LDS reads) against the VALU
+    kernel on the same bf16 tensors (segmented concat, band mix, nearest-2x source, shared / per-sample weights).  The MFMA
+    kernel rounds the band-mixed operand to bf16 as the forward conv does, the VALU kernel keeps it in float32: agreement
+    to 2^-8 of the largest gradient; without bands both multiply the same bf16 numbers (float32 summation order only)."""
+    from super_resolution_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    bf = lambda v: v.to(torch.bfloat16).cuda().contiguous()
+    Hs, Ws = H >> ups, W >> ups
+    if ups:
+        assert H % 2 == 0 and W % 2 == 0
+    cin = sum(segs)
+    xs = [bf(torch.randn(B, Hs, Ws, c, generator=g)) for c in segs]
+    lows = [[bf(torch.randn(B, H, W, c, generator=g)) for _ in range(3)] for c in segs] if bands else None
+    dyn = bf(torch.randn(B, H, W, cout, generator=g))
+    gt = torch.cat([torch.rand(B, H, W, 3, generator=g) * 2, torch.zeros(B, H, W, 1)], 3).cuda().contiguous() if bands else None
+    cc = L.Concat()
+    cc.nseg = len(segs)
+    cc.ups = ups
+    cc.bands = int(bands)
+    for i in range(len(segs)):
+        cc.x[i] = L.view(xs[i])
+        if bands:
+            cc.l2[i], cc.l4[i], cc.l8[i] = (L.view(k) for k in lows[i])
+    nb = B if per_sample else 1
+    st = L.stream_ptr(torch.device('cuda:0'))
+    out = []
+    for valu in (1, 0):
+        dw = torch.full((nb, 9, cout, cin), 7.0, device='cuda')
+        lib.sr_debug_wgrad_valu(valu)
+        try:
+            L.check(lib.sr_conv3x3_wgrad(1, B, H, W, C.byref(cc), L.ptr(gt), L.view(dyn), cout, int(per_sample), dw.data_ptr(), None, st))
+            torch.cuda.synchronize()
+        finally:
+            lib.sr_debug_wgrad_valu(0)
+        out.append(dw.cpu())
+    ref, got = out
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert scale > 1.0 and err <= (2.0 ** -8 if bands else 1e-5) * scale, (err, scale)
+
+
 # ------------------------------------------------------------------------------------------------------- layers
 @pytest.mark.parametrize('tag,cin,cout,B,h,w,pseed', [('c64_32', 64, 32, 4, 20, 24, 100), ('c192_64', 192, 64, 2, 16, 12, 104)])
 def test_fdconv_train_mode_gradients_vs_reference(sra, golden_r2, tag, cin, cout, B, h, w, pseed):
