@@ -137,7 +137,9 @@ int sr_fbm_masks_host(int H, int W, uint8_t* rows_host, uint8_t* cols_host);
 size_t sr_fbm_workspace_bytes(const sr_fbm_plan* plan, int B, int C);
 /* x: (B,H,W,C) view, or (B,H/2,W/2,C) when ups=1.  Writes L_k = lowpass_k(x) for k=2,4,8 into
  * l2/l4/l8 (B,H,W,C) and, if pooled != NULL, the spatial mean of every channel
- * (F.adaptive_avg_pool2d at FDConv.py:643) into pooled[b*pooled_ld + c] (float). */
+ * (F.adaptive_avg_pool2d at FDConv.py:643) into pooled[b*pooled_ld + c] (float).
+ * A band whose view has p == NULL is not produced (at least one must be given): the adjoint of the band mix in the
+ * training path needs one band per call, and the synthesis passes then run for that band only. */
 int sr_fbm_lowpass(const sr_fbm_plan* plan, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4, sr_view l8,
                    float* pooled, int pooled_ld, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -207,15 +207,17 @@ inline Epilogue to_epilogue(const sr_epilogue* e, long npix) {
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* weights,
                    long w_bstride, long w_lo_off, int cout, const Epilogue& ep, View out, hipStream_t st);
 
+// bmask: bit k set = band k (l2 / l4 / l8) is wanted; views of unwanted bands are never written (callers pass a copy of a
+// wanted one so that the layout checks see a valid view)
 int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8,
-                       float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st);
+                       float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st, int bmask = 7);
 // power-of-two fast path; returns SR_NOT_ELIGIBLE when the shape / alignment is not covered
 #define SR_NOT_ELIGIBLE (-100)
 int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
-                     int pooled_ld, void* ws, hipStream_t st);
+                     int pooled_ld, void* ws, hipStream_t st, int bmask = 7);
 // bf16 only: the three passes as real-basis DFT GEMMs on the matrix cores (SR_NOT_ELIGIBLE otherwise)
 int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
-                     int pooled_ld, void* ws, hipStream_t st);
+                     int pooled_ld, void* ws, hipStream_t st, int bmask = 7);
 int fbm_gates_launch(int dtype, int B, int H, int W, const Concat& in, const sr_layer_params& lp, float* gates,
                      hipStream_t st);
 // consumers of sr_fbm_gates_accumulate (device-side mirror of sr_gate_consumer)

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
                                                 const float* __restrict__ rowmask, const float2* __restrict__ t1,
                                                 float2* __restrict__ y2, float2* __restrict__ y4,
                                                 float2* __restrict__ y8, float* __restrict__ pooled, int pooled_ld,
-                                                int C) {
+                                                int C, int bmask) {
     const int lp = 31 - __clz(P);  // P is a power of two
     float2* buf0 = (float2*)smem;
     float2* buf1 = buf0 + H * P;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Ra
     const int nk[3] = {n2, n4, n8};
     float2* ys[3] = {y2, y4, y8};
     for (int k = 0; k < 3; ++k) {
-        if (kidx[k] < 0) continue;  // block-uniform
+        if (kidx[k] < 0 || !((bmask >> k) & 1)) continue;  // block-uniform
         const float* rm = rowmask + (k * 3 + variant) * H;
         const int tc = k == 0 ? (variant == 0 ? cuts.t[0] : (variant == 1 ? cuts.t[1] : cuts.t[2]))
                               : (k == 1 ? (variant == 0 ? cuts.t[3] : (variant == 1 ? cuts.t[4] : cuts.t[5]))
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
                                                     const int* __restrict__ cols2, const int* __restrict__ cols4,
                                                     const int* __restrict__ cols8, int n2, int n4, int n8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
-                                                    const float2* __restrict__ y8) {
+                                                    const float2* __restrict__ y8, int bmask) {
     const int lp = 31 - __clz(P);  // P is a power of two
     float2* bufA = (float2*)smem;
     float2* bufB = bufA + W * P;
@@ -491,6 +491,7 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
     const int* ck[3] = {cols2, cols4, cols8};
     const float2* ys[3] = {y2, y4, y8};
     for (int k = 0; k < 3; ++k) {
+        if (!((bmask >> k) & 1)) continue;  // block-uniform
         // selected field by field: an array of View structs indexed by the runtime k lived in scratch memory (128 B per lane)
         const View out = k == 0 ? l2 : (k == 1 ? l4 : l8);
         for (int it = threadIdx.x; it < W * P; it += blockDim.x) bufA[it] = make_float2(0.f, 0.f);
@@ -543,16 +544,16 @@ static Radix reversed(const Radix& a) {
 }
 
 int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8,
-                       float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st) {
+                       float* pooled, int pooled_ld, void* ws, size_t ws_bytes, hipStream_t st, int bmask) {
     const int H = pl->H, W = pl->W, C = x.C;
     const int PT = (C + 1) / 2;
     if (ws_bytes < sr_fbm_workspace_bytes(pl, B, C)) return SR_ERR_WORKSPACE;
     if (!g_force_generic_fft && !g_force_fft_lowpass) {
-        const int rc = fbm_lowpass_mfma(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st);
+        const int rc = fbm_lowpass_mfma(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st, bmask);
         if (rc != SR_NOT_ELIGIBLE) return rc;
     }
     if (!g_force_generic_fft) {
-        const int rc = fbm_lowpass_pow2(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st);
+        const int rc = fbm_lowpass_pow2(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st, bmask);
         if (rc != SR_NOT_ELIGIBLE) return rc;
     }
     const int n2 = pl->n[0], n4 = pl->n[1], n8 = pl->n[2];
@@ -594,14 +595,14 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
         fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1, pl->ucutW);
     SR_LAUNCH_CHECK();
     fbm_cols<<<g2, th_, lds_h, st>>>(H, W, PT, Ph, rh, rhi, cc, pl->tw_h, pl->colinfo, n2, n4, n8, pl->rowmask, t1, y2, y4, y8,
-                                     pooled, pooled_ld, C);
+                                     pooled, pooled_ld, C, bmask);
     SR_LAUNCH_CHECK();
     if (dtype == SR_F32)
         fbm_rows_inv<float><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rwi, rc3, pl->tw_w, pl->cols, pl->cols4,
-                                                    pl->cols8, n2, n4, n8, y2, y4, y8);
+                                                    pl->cols8, n2, n4, n8, y2, y4, y8, bmask);
     else
         fbm_rows_inv<bf16_t><<<g1, tw_, lds_w, st>>>(l2, l4, l8, pair_out, H, W, C, PT, Pw, rwi, rc3, pl->tw_w, pl->cols, pl->cols4,
-                                                     pl->cols8, n2, n4, n8, y2, y4, y8);
+                                                     pl->cols8, n2, n4, n8, y2, y4, y8, bmask);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -791,7 +792,18 @@ extern "C" size_t sr_fbm_workspace_bytes(const sr_fbm_plan* pl, int B, int C) {
 
 extern "C" int sr_fbm_lowpass(const sr_fbm_plan* pl, int dtype, int B, sr_view x, int ups, sr_view l2, sr_view l4,
                               sr_view l8, float* pooled, int pooled_ld, void* ws, size_t ws_bytes, void* stream) {
-    SR_REQUIRE(pl && dtype_ok(dtype) && B > 0 && x.p && l2.p && l4.p && l8.p && ws);
+    SR_REQUIRE(pl && dtype_ok(dtype) && B > 0 && x.p && ws);
+    // a band whose view has p == NULL is not wanted (the adjoint of the band mix needs one band per call)
+    sr_view* outs[3] = {&l2, &l4, &l8};
+    int bmask = 0, first = -1;
+    for (int k = 0; k < 3; ++k)
+        if (outs[k]->p) {
+            bmask |= 1 << k;
+            if (first < 0) first = k;
+        }
+    SR_REQUIRE(bmask != 0);
+    for (int k = 0; k < 3; ++k)
+        if (!outs[k]->p) *outs[k] = *outs[first];  // never written; keeps the layout checks of the kernels' launchers uniform
     SR_REQUIRE(x.C > 0 && l2.C == x.C && l4.C == x.C && l8.C == x.C);
     SR_REQUIRE(x.c0 >= 0 && l2.c0 >= 0 && l4.c0 >= 0 && l8.c0 >= 0);
     SR_REQUIRE(view_block_ok(x) && view_block_ok(l2) && view_block_ok(l4) && view_block_ok(l8));
@@ -799,7 +811,7 @@ extern "C" int sr_fbm_lowpass(const sr_fbm_plan* pl, int dtype, int B, sr_view x
     SR_REQUIRE(!pooled || pooled_ld >= x.C);
     const long npix = (long)pl->H * pl->W;
     return fbm_lowpass_launch(pl, dtype, B, to_view(x, ups ? npix / 4 : npix), ups ? 1 : 0, to_view(l2, npix),
-                              to_view(l4, npix), to_view(l8, npix), pooled, pooled_ld, ws, ws_bytes, (hipStream_t)stream);
+                              to_view(l4, npix), to_view(l8, npix), pooled, pooled_ld, ws, ws_bytes, (hipStream_t)stream, bmask);
 }
 
 // ---- the one entry point that allocates nothing --------------------------------------------------------------------

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, cons
                                                 int a8, const float* __restrict__ rowmask,
                                                 const float2* __restrict__ t1, float2* __restrict__ y2,
                                                 float2* __restrict__ y4, float2* __restrict__ y8,
-                                                float* __restrict__ pooled, int pooled_ld, int C) {
+                                                float* __restrict__ pooled, int pooled_ld, int C, int bmask) {
     constexpr int H = N;
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(THREADS, 4) void cols(int W, int PT, Inter im, cons
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const int pos = col < a ? col : (col > W - a ? col - (W - nk) : -1);
-        if (pos < 0) return;  // block-uniform
+        if (pos < 0 || !((bmask >> k) & 1)) return;  // block-uniform
         const float* rm = rowmask + (k * 3 + variant) * H;
         // the first inverse pass takes the saved operands, scaled by the row mask
         auto lm = [&](int r, int, int q, int t) {
@@ -415,7 +415,7 @@ template <typename T, int N, int P, bool BLK, bool PZ>
 __global__ __launch_bounds__(THREADS, 4) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, int a4, int a8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
-                                                    const float2* __restrict__ y8) {
+                                                    const float2* __restrict__ y8, int bmask) {
     float2* buf = (float2*)smem_fast;
     const float2* twl = stage_twiddles<N>(tw, buf + N * P);
     unsigned bx, by;
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(THREADS, 4) void rows_inv(View l2, View l4, View l8
     float2 pre[3][IT0][R0];
     auto fetch = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
+        if (!((bmask >> k) & 1)) return;  // block-uniform
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(THREADS, 4) void rows_inv(View l2, View l4, View l8
     }
     auto band = [&](auto kc) {  // k as a compile-time constant: it selects the pruned first pass
         constexpr int k = decltype(kc)::value;
+        if (!((bmask >> k) & 1)) return;  // block-uniform
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
@@ -514,7 +516,7 @@ static int launch_rows_fwd(View x, int ups, bool shortcut, int B, int H, int PT,
 
 template <typename T, int N, bool BLK>
 static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inter im, const sr_fbm_plan* pl,
-                           const float2* y2, const float2* y4, const float2* y8, hipStream_t st) {
+                           const float2* y2, const float2* y4, const float2* y8, int bmask, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
     // standard masks along W: operand ranges 2..5 (k = 2, 4) and 1..6 (k = 8) of a radix-8 first pass are empty
@@ -523,11 +525,11 @@ static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inte
     if (pz) {
         SR_LDS_ATTR(lds, rows_inv<T, N, P, BLK, true>);
         rows_inv<T, N, P, BLK, true><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
-                                                                            pl->half[1], pl->half[2], y2, y4, y8);
+                                                                            pl->half[1], pl->half[2], y2, y4, y8, bmask);
     } else {
         SR_LDS_ATTR(lds, rows_inv<T, N, P, BLK, false>);
         rows_inv<T, N, P, BLK, false><<<dim3(B * H, cdiv(PT, P)), THREADS, lds, st>>>(l2, l4, l8, H, PT, im, pl->tw_w, pl->half[0],
-                                                                            pl->half[1], pl->half[2], y2, y4, y8);
+                                                                            pl->half[1], pl->half[2], y2, y4, y8, bmask);
     }
     SR_LAUNCH_CHECK();
     return SR_OK;
@@ -535,7 +537,7 @@ static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inte
 
 template <int N, bool BLK>
 static int launch_cols(bool shortcut, int B, int W, int PT, int C, Inter im, const sr_fbm_plan* pl, const float2* t1, float2* y2,
-                       float2* y4, float2* y8, float* pooled, int pooled_ld, hipStream_t st) {
+                       float2* y4, float2* y8, float* pooled, int pooled_ld, int bmask, hipStream_t st) {
     constexpr int P = pairs_for(N);
     const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
     bool pz = first_radix(N) == 8;  // every variant of every row mask must leave the standard ranges empty
@@ -545,7 +547,7 @@ static int launch_cols(bool shortcut, int B, int W, int PT, int C, Inter im, con
     do {                                                                                                                     \
         SR_LDS_ATTR(lds, cols<N, P, BLK, PZ_, UPS_>); \
         cols<N, P, BLK, PZ_, UPS_><<<grid, THREADS, lds, st>>>(W, PT, im, pl->tw_h, pl->half[0], pl->half[1], pl->half[2],    \
-                                                             pl->rowmask, t1, y2, y4, y8, pooled, pooled_ld, C);             \
+                                                             pl->rowmask, t1, y2, y4, y8, pooled, pooled_ld, C, bmask);      \
     } while (0)
     if constexpr (N >= 128) {
         if (shortcut) {
@@ -577,7 +579,7 @@ static bool pow2_ok(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; 
 
 template <typename T>
 static int run_all(const sr_fbm_plan* pl, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
-                   int pooled_ld, void* ws, bool blk_x, bool blk_o, hipStream_t st) {
+                   int pooled_ld, void* ws, bool blk_x, bool blk_o, int bmask, hipStream_t st) {
     const int H = pl->H, W = pl->W, C = x.C;
     const int PT = C / 2;
     Inter im;
@@ -597,18 +599,18 @@ static int run_all(const sr_fbm_plan* pl, int B, View x, int ups, View l2, View 
     if (blk_x) { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, true>(x, ups, shortcut, B, H, PT, im, pl, t1, st))); }
     else { SR_DISPATCH_N(W, rc = (launch_rows_fwd<T, NN, false>(x, ups, shortcut, B, H, PT, im, pl, t1, st))); }
     if (rc != SR_OK) return rc;
-    if (blk_c) { SR_DISPATCH_N(H, rc = (launch_cols<NN, true>(shortcut, B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
-    else { SR_DISPATCH_N(H, rc = (launch_cols<NN, false>(shortcut, B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, st))); }
+    if (blk_c) { SR_DISPATCH_N(H, rc = (launch_cols<NN, true>(shortcut, B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, bmask, st))); }
+    else { SR_DISPATCH_N(H, rc = (launch_cols<NN, false>(shortcut, B, W, PT, C, im, pl, t1, y2, y4, y8, pooled, pooled_ld, bmask, st))); }
     if (rc != SR_OK) return rc;
-    if (blk_o) { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, true>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, st))); }
-    else { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, false>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, st))); }
+    if (blk_o) { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, true>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, bmask, st))); }
+    else { SR_DISPATCH_N(W, rc = (launch_rows_inv<T, NN, false>(l2, l4, l8, B, H, PT, im, pl, y2, y4, y8, bmask, st))); }
     return rc;
 }
 
 }  // namespace fast
 
 int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
-                     int pooled_ld, void* ws, hipStream_t st) {
+                     int pooled_ld, void* ws, hipStream_t st, int bmask) {
     using namespace fast;
     const int H = pl->H, W = pl->W, C = x.C;
     if (!pl->contiguous || !pow2_ok(H) || !pow2_ok(W) || (C & 1)) return SR_NOT_ELIGIBLE;
@@ -623,7 +625,7 @@ int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     // the row-major lane order pays for channel-blocked tensors (a row of 8 channels is contiguous)
     auto is_blocked = [&](const View& v) { return v.ld == 8 && v.c0 % 8 == 0 && C % 8 == 0; };
     const bool blk_x = is_blocked(x), blk_o = is_blocked(l2) && is_blocked(l4) && is_blocked(l8);
-    if (dtype == SR_F32) return run_all<float>(pl, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, blk_x, blk_o, st);
-    return run_all<bf16_t>(pl, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, blk_x, blk_o, st);
+    if (dtype == SR_F32) return run_all<float>(pl, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, blk_x, blk_o, bmask, st);
+    return run_all<bf16_t>(pl, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, blk_x, blk_o, bmask, st);
 }
 }  // namespace sr

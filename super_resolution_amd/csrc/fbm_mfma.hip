@@ -330,6 +330,9 @@ struct SynArgs {
     int tile0;          // first basis tile of this launch (waves take tiles tile0 .. tile0 + 15; M > 512 takes two launches)
     const h16* basis;   // fragment-major [pad32(M)][16 * nks_tab]
     int nks_tab;
+    int bmask;          // bit k set = band k is produced
+    int bfirst;         // first wanted band
+    int bnext[3];       // wanted band after band k, or -1
 };
 
 // SHARED = true: synthesis along H (one staged coefficient image per item group, mask weights through the window rows,
@@ -361,7 +364,8 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
     for (int k = 0; k < 3; ++k) wts[k] = SHARED ? a.win[k * WIN_ROWS + (tid >> 4)] : make_float2(0.f, 0.f);
     // SHARED: the narrower bands exist for the first item groups only (3, 2 or 1 bands of work per group); with the sample
     // index fastest a workgroup's groups (grp = blockIdx + n * gridDim) are spread over the whole item range
-    const int gpb = (a.nitems[0] + G - 1) / G, ngroups = a.NB * gpb;
+    // (groups cover the items of the widest WANTED band: the first band that runs in a group stages the next image)
+    const int gpb = (sel3(a.bfirst, a.nitems[0], a.nitems[1], a.nitems[2]) + G - 1) / G, ngroups = a.NB * gpb;
     // loader: rows r0 + 32 i, 16-byte chunk ch (item ch >> 2); tl = fresh_tid()
     auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[NR]) {
         const int ch = tl & 15, r0 = tl >> 4, oct = ch & 3;
@@ -389,16 +393,17 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
         }
     };
 
-    int grp = blockIdx.x, band = 0;
+    const int band_first = SHARED ? 0 : a.bfirst;
+    int grp = blockIdx.x, band = band_first;
     if (grp >= ngroups) return;
     uint4 pre[NR];
-    fetch(tid, grp, 0, pre);
-    stash(tid, pre, lds, 0);
+    fetch(tid, grp, band, pre);
+    stash(tid, pre, lds, band);
     __syncthreads();
     for (unsigned it = 0;; ++it) {
-        int ngrp = grp, nband = band + 1;
-        if (SHARED || nband == 3) {
-            nband = 0;
+        int ngrp = grp, nband = SHARED ? -1 : sel3(band, a.bnext[0], a.bnext[1], a.bnext[2]);
+        if (nband < 0) {
+            nband = band_first;
             ngrp = grp + gridDim.x;
         }
         const bool more = ngrp < ngroups;
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
 #pragma unroll 1
             for (int k = SHARED ? 0 : band; k < (SHARED ? 3 : band + 1); ++k) {
                 const int nit = sel3(k, a.nitems[0], a.nitems[1], a.nitems[2]);
-                if (i0 >= nit) continue;
+                if (i0 >= nit || !((a.bmask >> k) & 1)) continue;
                 const int ksm = sel3(k, a.ksm[0], a.ksm[1], a.ksm[2]);
                 const int kend = ksm + (SHARED ? sel3(k, a.nwin[0], a.nwin[1], a.nwin[2]) : 0);
                 const char* wbase = winimg + (k * WIN_ROWS - 16 * ksm) * ROWB;  // window row of k-step ks: k * 32 + 16 (ks - ksm)
@@ -562,16 +567,16 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
         }
     };
 
-    int grp = blockIdx.x, band = 0;
+    int grp = blockIdx.x, band = a.bfirst;
     if (grp >= ngroups) return;
     uint4 pre[8];
-    fetch(tid, grp, 0, pre);
-    stash(tid, pre, lds, 0);
+    fetch(tid, grp, band, pre);
+    stash(tid, pre, lds, band);
     __syncthreads();
     for (unsigned it = 0;; ++it) {
-        int ngrp = grp, nband = band + 1;
-        if (nband == 3) {
-            nband = 0;
+        int ngrp = grp, nband = sel3(band, a.bnext[0], a.bnext[1], a.bnext[2]);
+        if (nband < 0) {
+            nband = a.bfirst;
             ngrp = grp + gridDim.x;
         }
         const bool more = ngrp < ngroups;
@@ -805,8 +810,15 @@ int g_mfma_cus = 0;
 int g_mfma_no_fold = 0;  // debug hook: W-synthesis without the even / odd fold
 
 int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
-                     int pooled_ld, void* ws, hipStream_t st) {
+                     int pooled_ld, void* ws, hipStream_t st, int bmask) {
     using namespace mf;
+    bmask &= 7;
+    if (!bmask) return SR_ERR_ARG;
+    int bfirst = 0, bnext[3] = {-1, -1, -1};
+    while (!((bmask >> bfirst) & 1)) ++bfirst;
+    for (int k = 0; k < 3; ++k)
+        for (int j = 2; j > k; --j)
+            if ((bmask >> j) & 1) bnext[k] = j;
     if (dtype != SR_BF16 || !pl->mf_ok) return SR_NOT_ELIGIBLE;
     const int H = pl->H, W = pl->W, C = x.C;
     if (!view32_ok(x, C) || !view32_ok(l2, C) || !view32_ok(l4, C) || !view32_ok(l8, C)) return SR_NOT_ELIGIBLE;
@@ -823,7 +835,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     U[2] = U[1] + (size_t)NB * usz[1];
     if ((size_t)((char*)(U[2] + (size_t)NB * usz[2]) - (char*)ws) > sr_fbm_workspace_bytes(pl, B, C)) return SR_NOT_ELIGIBLE;
     auto grid_for = [&](long items, int G) { return (int)std::min<long>((long)NB * ((items + G - 1) / G), g_mfma_cus); };
-    const int jw_real = pl->mf_nw[0], nh_real = pl->mf_nhk[0];
+    const int nh_real = pl->mf_nhk[0];
     // wide instances: K up to 544 in the analysis (34 k-steps), up to 272 in the synthesis (17 k-steps)
     const bool wide_aw = W > 512, wide_ah = H > 512, wide_s = pl->mf_ld_qw > 256 || pl->mf_ld_ph > 256;
     auto lds_ana = [](bool wide) { return 2 * (wide ? 34 : 32) * 16 * 128; };
@@ -872,7 +884,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     a2.M = nh;
     a2.NB = NB;
     a2.CG = CG;
-    a2.nitems = jw_real + (jw_real & 1);
+    a2.nitems = pl->mf_nw[bfirst] + (pl->mf_nw[bfirst] & 1);  // coefficient columns of the widest wanted band
     a2.scale = 1.0f / 16.0f;
     a2.pool_scale = 4.0f / std::sqrt((float)H * (float)W);
     for (int t0 = 0; t0 < nh / 32; t0 += 8) {
@@ -904,6 +916,9 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s3.dst_i[k] = 32;
         s3.nitems[k] = pl->mf_nw[k];
     }
+    s3.bmask = bmask;
+    s3.bfirst = bfirst;
+    for (int k = 0; k < 3; ++k) s3.bnext[k] = bnext[k];
     s3.win = (const float2*)pl->mf_win;
     s3.M = pad_to(H, 32);
     s3.Mv = H;
@@ -915,10 +930,10 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s3.tile0 = t0;
         if (wide_s) {
             SR_LDS_ATTR(lds_syn, mf_synthesis<true, 17>);
-            mf_synthesis<true, 17><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
+            mf_synthesis<true, 17><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, lds_syn, st>>>(s3);
         } else {
             SR_LDS_ATTR(lds_syn, mf_synthesis<true, 16>);
-            mf_synthesis<true, 16><<<grid_for(pl->mf_nw[0], 4), THREADS, lds_syn, st>>>(s3);
+            mf_synthesis<true, 16><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, lds_syn, st>>>(s3);
         }
         SR_LAUNCH_CHECK();
     }
@@ -935,6 +950,9 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         s4.out[k] = outs[k];
         s4.nitems[k] = H;
     }
+    s4.bmask = bmask;
+    s4.bfirst = bfirst;
+    for (int k = 0; k < 3; ++k) s4.bnext[k] = bnext[k];
     s4.Wout = W;
     s4.M = pad_to(W, 32);
     s4.Mv = W;

@@ -268,13 +268,13 @@ class _FDConvFn(torch.autograd.Function):
                                         L.view(dxd), L.view(dl2), L.view(dl4), L.view(dl8), dz.data_ptr(), st), 'sr_fbm_backward')
             # 4. the band branches back through the (self-adjoint) low-pass: plane k of lowpass(dl_k)
             ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
+            # (a view with a NULL pointer = band not wanted: each call synthesises one band only)
             adj = []
-            scratch = [torch.empty_like(xn), torch.empty_like(xn)]
             for k, src in enumerate((dl2, dl4, dl8)):
                 out = torch.empty_like(xn)
-                planes = [scratch[0], scratch[1]]
-                planes.insert(k, out)
-                L.check(lib.sr_fbm_lowpass(plan, code, B, L.view(src), 0, L.view(planes[0]), L.view(planes[1]), L.view(planes[2]),
+                planes = [L.View(), L.View(), L.View()]
+                planes[k] = L.view(out)
+                L.check(lib.sr_fbm_lowpass(plan, code, B, L.view(src), 0, planes[0], planes[1], planes[2],
                                            None, 0, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass (adjoint)')
                 adj.append(out)
             # 5. the small weight path on torch autograd: dW_b -> parameters and pooled means

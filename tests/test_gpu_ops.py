@@ -115,20 +115,48 @@ def run_lowpass(L, x, dt, ups=0):
         lib.sr_debug_force_fft_lowpass(-1)
 
 
-def _run_lowpass(L, lib, x, dt, ups):
+def _run_lowpass(L, lib, x, dt, ups, want=(0, 1, 2)):
     B, Cc, H, W = x.shape
     Ho, Wo = H << ups, W << ups
     plan = C.c_void_p()
     L.check(lib.sr_fbm_plan_create(Ho, Wo, C.byref(plan)))
     xn = nhwc(x, dt)
     bands = [torch.full((B, Ho, Wo, Cc), float('nan'), device='cuda:0', dtype=dt) for _ in range(3)]
+    views = [L.view(bands[k]) if k in want else L.View() for k in range(3)]  # p == NULL: band not wanted
     pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
     ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
-    L.check(lib.sr_fbm_lowpass(plan, L.dtype_code(dt), B, L.view(xn), ups, L.view(bands[0]), L.view(bands[1]),
-                               L.view(bands[2]), pooled.data_ptr(), Cc, ws.data_ptr(), ws.numel(), st(L)))
+    L.check(lib.sr_fbm_lowpass(plan, L.dtype_code(dt), B, L.view(xn), ups, views[0], views[1], views[2], pooled.data_ptr(), Cc,
+                               ws.data_ptr(), ws.numel(), st(L)))
     torch.cuda.synchronize()
     lib.sr_fbm_plan_destroy(plan)
     return [nchw(b) for b in bands], pooled.cpu()
+
+
+@pytest.mark.parametrize('shape,dt,fft', [((2, 32, 64, 64), torch.bfloat16, 0), ((1, 64, 48, 80), torch.bfloat16, 0),
+                                          ((1, 32, 522, 532), torch.bfloat16, 0), ((1, 6, 128, 64), torch.float32, 1),
+                                          ((2, 32, 64, 128), torch.bfloat16, 1), ((1, 5, 33, 35), torch.float32, 1),
+                                          ((1, 4, 58, 36), torch.float32, 1)])
+def test_fbm_lowpass_band_selection(L, shape, dt, fft):
+    """A band whose view is NULL is not produced (the adjoint of the band mix wants one band per call): the wanted
+    planes are bit-identical to those of the three-band call, on the matrix-core path, the power-of-two FFT and the
+    any-size FFT; the spatial means still come out."""
+    lib = L.lib()
+    x = torch.from_numpy(gp.signed_input(shape, 23)).to(dt).float()
+    lib.sr_debug_force_fft_lowpass(1 if fft else 0)
+    try:
+        full, pooled = _run_lowpass(L, lib, x, dt, 0)
+        for want in ((0,), (1,), (2,), (0, 2), (1, 2)):
+            got, pooled_w = _run_lowpass(L, lib, x, dt, 0, want)
+            for k in range(3):
+                if k in want:
+                    assert torch.equal(got[k], full[k]), (shape, want, k)
+                else:
+                    assert torch.isnan(got[k]).all()  # untouched
+            assert torch.equal(pooled_w, pooled)
+        with pytest.raises(Exception):
+            _run_lowpass(L, lib, x, dt, 0, ())
+    finally:
+        lib.sr_debug_force_fft_lowpass(-1)
 
 
 @pytest.mark.parametrize('shape', [(2, 6, 12, 12), (1, 5, 33, 35), (2, 32, 40, 48), (1, 64, 64, 64), (1, 8, 130, 77),
