@@ -429,7 +429,7 @@ def run_train(args, world, rank, dev, dist):
                    'parallelism': 'data parallel x%d, bucketed gradient all-reduce of %.1f M parameters (local BatchNorm statistics)' % (world, nparam / 1e6),
                    'loss_first_last': [losses[0], losses[-1]], 'loss_finite': bool(np.isfinite(losses).all()),
                    'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv forward + operand gradient (MFMA in bf16 mode) + weight gradient (fp32-accumulate VALU kernel)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv forward + operand gradient + weight gradient: on the matrix cores in bf16 mode (float32 accumulation), VALU kernels in f32 mode',
                      'achieved': flops / step_s / 1e12, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
                      'note': 'whole-step time (no per-kernel events in the training path yet); algorithmic conv FLOPs = 3 x forward'},

@@ -247,7 +247,8 @@ int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat* in, const 
 int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_view l2, sr_view l4, sr_view l8, const float* gates, sr_view da,
                     sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, void* stream);
 /* backward of the three gate convs (FDConv.py:460-461) and assembly of the layer's input gradient:
- *   dgate_w [3][cin][9], dgate_b [3] (float32, OVERWRITTEN; same atomics remark as sr_conv3x3_wgrad)
+ *   dgate_w [3][cin][9], dgate_b [3] (float32, OVERWRITTEN; same atomics remark as sr_conv3x3_wgrad); both NULL: not
+ *   computed (the bf16 training path gets them from sr_conv3x3_wgrad with the logit gradients in the place of dy)
  *   dx_out = dx_direct + a2 + a4 + a8 + conv3x3^T(dlogits; gate_w) + dpooled[b][c] / (H W)
  * a_k = sr_fbm_lowpass plane k of dl_k (the box low-pass is self-adjoint: a real symmetric mask between a unitary
  * transform pair); dpooled (B, dpooled_ld) float or NULL: gradient wrt the pooled means (F.adaptive_avg_pool2d at

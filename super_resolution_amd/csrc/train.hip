@@ -577,7 +577,7 @@ extern "C" int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_vie
 extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, const float* dlogits, const sr_layer_params* lp,
                                      sr_view dx_direct, sr_view a2, sr_view a4, sr_view a8, const float* dpooled, int dpooled_ld,
                                      sr_view dx_out, float* dgate_w, float* dgate_b, void* stream) {
-    SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && dlogits && lp && dgate_w && dgate_b && x.C > 0 && x.C == lp->cin);
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && dlogits && lp && (!dgate_w) == (!dgate_b) && x.C > 0 && x.C == lp->cin);
     SR_REQUIRE(lp->gate_w[0] && lp->gate_w[1] && lp->gate_w[2]);
     SR_REQUIRE(!dpooled || dpooled_ld >= x.C);
     const int C = x.C;
@@ -585,8 +585,10 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
     for (const sr_view* v : vs) SR_REQUIRE(plain_view_ok(*v, C));
     const long npix = (long)H * W, total = (long)B * npix;
     hipStream_t st = (hipStream_t)stream;
-    SR_HIP(hipMemsetAsync(dgate_w, 0, (size_t)27 * C * sizeof(float), st));
-    SR_HIP(hipMemsetAsync(dgate_b, 0, 3 * sizeof(float), st));
+    if (dgate_w) {
+        SR_HIP(hipMemsetAsync(dgate_w, 0, (size_t)27 * C * sizeof(float), st));
+        SR_HIP(hipMemsetAsync(dgate_b, 0, 3 * sizeof(float), st));
+    }
     const int ppw = 16;  // pixels per wavefront
     dim3 g1(cdiv(total, 4 * ppw), cdiv(C, 64));
     const int ppb = total >= 512L * 512 ? 2048 : 512;  // pixels per workgroup: ~2 workgroups per CU and channel tile at the training sizes
@@ -596,8 +598,10 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
         input_grad_kernel<T><<<g1, 256, 0, st>>>(B, H, W, C, dlogits, *lp, to_view(dx_direct, npix), to_view(a2, npix),         \
                                                  to_view(a4, npix), to_view(a8, npix), dpooled, dpooled_ld, to_view(dx_out, npix), ppw); \
         SR_LAUNCH_CHECK();                                                                                                       \
-        gate_wgrad_kernel<T><<<g2, 256, 0, st>>>(B, H, W, C, to_view(x, npix), dlogits, dgate_w, dgate_b, ppb);                  \
-        SR_LAUNCH_CHECK();                                                                                                       \
+        if (dgate_w) {                                                                                                           \
+            gate_wgrad_kernel<T><<<g2, 256, 0, st>>>(B, H, W, C, to_view(x, npix), dlogits, dgate_w, dgate_b, ppb);              \
+            SR_LAUNCH_CHECK();                                                                                                   \
+        }                                                                                                                        \
     } while (0)
     if (dtype == SR_F32) SR_GB(float);
     else SR_GB(bf16_t);

@@ -288,12 +288,25 @@ class _FDConvFn(torch.autograd.Function):
             for n, gch in zip(_WEIGHT_PATH, got[1:]):
                 grads[n] = gch
             # 6. gate convs + assembly of the input gradient
-            dgw = torch.empty(3, cin, 9, dtype=torch.float32, device=dev)
-            dgb = torch.empty(3, dtype=torch.float32, device=dev)
             dxn = torch.empty_like(xn)
+            if xn.dtype == torch.bfloat16 and cin % 32 == 0:
+                # gate-conv weight gradients on the matrix cores: the weight-gradient kernel with the logit gradients (three
+                # channels, padded to one 32-wide tile, bf16 like every other dy of this mode) in the place of dy
+                dzp = torch.zeros(B, H, W, 32, dtype=torch.bfloat16, device=dev)
+                dzp[..., :4] = dz
+                dw32 = torch.empty(1, 9, 32, cin, dtype=torch.float32, device=dev)
+                L.check(lib.sr_conv3x3_wgrad(code, B, H, W, C.byref(_concat1(xn)), None, L.view(dzp), 32, 0, dw32.data_ptr(), None, st),
+                        'sr_conv3x3_wgrad (gate convs)')
+                dgw = dw32[0, :, :3, :].permute(1, 2, 0).contiguous()
+                dgb = dz.sum((0, 1, 2))[:3]
+                gw_ptr = gb_ptr = None
+            else:
+                dgw = torch.empty(3, cin, 9, dtype=torch.float32, device=dev)
+                dgb = torch.empty(3, dtype=torch.float32, device=dev)
+                gw_ptr, gb_ptr = dgw.data_ptr(), dgb.data_ptr()
             L.check(lib.sr_fbm_gates_backward(code, B, H, W, L.view(xn), dz.data_ptr(), C.byref(lp), L.view(dxd), L.view(adj[0]),
-                                              L.view(adj[1]), L.view(adj[2]), dpooled.data_ptr(), cin, L.view(dxn), dgw.data_ptr(),
-                                              dgb.data_ptr(), st), 'sr_fbm_gates_backward')
+                                              L.view(adj[1]), L.view(adj[2]), dpooled.data_ptr(), cin, L.view(dxn), gw_ptr,
+                                              gb_ptr, st), 'sr_fbm_gates_backward')
             for k in range(3):
                 grads['FBM.freq_weight_conv_list.%d.weight' % k] = dgw[k].reshape(1, cin, 3, 3)
                 grads['FBM.freq_weight_conv_list.%d.bias' % k] = dgb[k:k + 1]
