@@ -178,9 +178,14 @@ class FDConv(nn.Conv2d):
     def group_map(self):
         """uint8 (3*cout, 3*cin//2+1) frequency-group id of every rfft2 bin, from `indices`."""
         idx = self.indices[0]
+        key = (idx.data_ptr(), idx._version, idx.device)
+        hit = self._sr_cache.get('gmap')  # built once per placement: a training step asks for it twice per layer
+        if hit is not None and hit[0] == key:
+            return hit[1]
         gmap = torch.zeros(self.out_channels * 3, self.in_channels * 3 // 2 + 1, dtype=torch.uint8, device=idx.device)
         for g in range(idx.shape[1]):
             gmap[idx[0, g], idx[1, g]] = g
+        self._sr_cache['gmap'] = (key, gmap)
         return gmap
 
     def sr_layer_params(self, dtype):
