@@ -178,27 +178,22 @@ __device__ __forceinline__ void fft_pass_prime(const float2* __restrict__ src, f
         const int j = o / nu;
         const int jhi = j / Ns, k = j - jhi * Ns;
         const int ks = k * tstep;  // pass twiddle of operand t: tw[t * ks], t * ks < N
-        float2 z0 = src[j * P + p];
-        if (premul) {
-            z0.x *= premul[j];
-            z0.y *= premul[j];
-        }
-        float2 a = z0, bsum = make_float2(0.f, 0.f);
+        // complex numbers as float2v: sums / differences / scaled accumulations are one packed instruction each
+        const float2v* srcv = (const float2v*)src;
+        float2v a = srcv[j * P + p];
+        if (premul) a *= premul[j];
+        float2v bsum = {0.f, 0.f};
         int m = 0;      // (u * t) mod R
         int q1 = 0, q2 = R * ks;  // t * ks and (R - t) * ks
         for (int t = 1; t < nt; ++t) {
             m += u;
             if (m >= R) m -= R;
             const int s1 = j + t * NR, s2 = j + (R - t) * NR;
-            float2 x1 = src[s1 * P + p], x2 = src[s2 * P + p];
+            float2v z1 = srcv[s1 * P + p], z2 = srcv[s2 * P + p];
             if (premul) {
-                const float m1 = premul[s1], m2 = premul[s2];
-                x1.x *= m1;
-                x1.y *= m1;
-                x2.x *= m2;
-                x2.y *= m2;
+                z1 *= premul[s1];
+                z2 *= premul[s2];
             }
-            float2 z1 = x1, z2 = x2;
             if (!notw) {  // block-uniform
                 q1 += ks;
                 q2 -= ks;
@@ -207,18 +202,18 @@ __device__ __forceinline__ void fft_pass_prime(const float2* __restrict__ src, f
                     w1.y = -w1.y;
                     w2.y = -w2.y;
                 }
-                z1 = cmul(x1, w1);
-                z2 = cmul(x2, w2);
+                // (x + i y)(c + i s) = x (c, s) + y (-s, c)
+                const float2v c1 = {w1.x, w1.y}, r1 = {-w1.y, w1.x}, c2 = {w2.x, w2.y}, r2 = {-w2.y, w2.x};
+                z1 = __builtin_elementwise_fma(z1.yy, r1, z1.xx * c1);
+                z2 = __builtin_elementwise_fma(z2.yy, r2, z2.xx * c2);
             }
             const float2 cs = tw[m * NR];  // (cos, -sin) of 2 pi u t / R
-            a.x += (z1.x + z2.x) * cs.x;
-            a.y += (z1.y + z2.y) * cs.x;
-            bsum.x += (z1.x - z2.x) * cs.y;
-            bsum.y += (z1.y - z2.y) * cs.y;
+            const float2v cc = {cs.x, cs.x}, ss = {cs.y, cs.y};
+            a = __builtin_elementwise_fma(z1 + z2, cc, a);
+            bsum = __builtin_elementwise_fma(z1 - z2, ss, bsum);
         }
-        // forward: X[u] = a - i * (-b') with b' = sum d * (-sin) -> X[u] = a + i * bsum rotated; written out explicitly:
         // e^{-i th} -> z1 (cos - i sin) + z2 (cos + i sin) = (z1 + z2) cos - i (z1 - z2) sin; cs.y = -sin, so
-        // -i (z1 - z2) sin = i (z1 - z2) cs.y = i * bsum-term.  i * (x + i y) = (-y, x).
+        // -i (z1 - z2) sin = i (z1 - z2) cs.y = i * bsum (forward);  i * (x + i y) = (-y, x).
         float2 up, um;
         if (!INV) {
             up = make_float2(a.x - bsum.y, a.y + bsum.x);  // X[u]
