@@ -213,7 +213,7 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
 template <int MT, bool BANDS, int SPLIT>
 __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, long w_lo_off,
-                                                         int cin, int cout, Epilogue ep, View out, unsigned total) {
+                                                         int cin, int cout, Epilogue ep, View out, unsigned total, int wmap) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int STAGE_PX = NPIX * 64;
     constexpr int WSLAB = 9 * MT * 32 * 64;
@@ -221,9 +221,12 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
     char* const lds_wb = lds_wa + WSLAB;
     const int tilesx = (W + MTW - 1) / MTW;
     const unsigned tiles = (unsigned)tilesx * ((H + MTH - 1) / MTH);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // wmap (A/B hook): physical waves {0, 1, 4, 5} multiply and {2, 3, 6, 7} load, so that -- waves being dealt to the four
+    // SIMDs round-robin -- two SIMDs hold the MFMA waves and the other two the loaders
+    const int lane = threadIdx.x & 63;
+    const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wmap ? ((pw & 2) * 2 + (pw & 1) + ((pw >> 2) << 1)) : pw;  // scalar
+    const int tid = wave * 64 + lane;
     const bool loader = wave >= 4;
     const int r = lane & 31, hk = lane >> 5;
     const int nchunks = cin / 32;
@@ -679,7 +682,7 @@ static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates
     int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
     if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-    conv3x3_mfma_bf16<MT, BANDS, SPLIT><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk);
+    conv3x3_mfma_bf16<MT, BANDS, SPLIT><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk, g_split_two_pass);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, in
         for (int t = 0; t < 9; ++t) gw[k][t] = lp.gate_w[k][cc * 9 + t];
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long q0 = wave * pix_per_wave, q1 = min(total, q0 + pix_per_wave);
+    // branch-free body (clamped neighbour address, validity as a factor), four pixels deep: the loads of several pixels
+    // are in flight together -- one pixel at a time the wave is a chain of dependent memory round trips
+#pragma unroll 4
     for (long pg = q0; pg < q1; ++pg) {
         const int b = (int)(pg / npix);
         const long p = pg - (long)b * npix;
@@ -417,9 +420,10 @@ __global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, in
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
-            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;  // wave-uniform
-            const float4 d = ((const float4*)dz)[(long)b * npix + (long)hh * W + ww];
-            gsum += gw[0][t] * d.x + gw[1][t] * d.y + gw[2][t] * d.z;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;  // wave-uniform
+            const float4 d = ((const float4*)dz)[(long)b * npix + (long)min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1)];
+            const float f = ok ? 1.f : 0.f;
+            gsum += f * (gw[0][t] * d.x + gw[1][t] * d.y + gw[2][t] * d.z);
         }
         if (live) Elem<T>::st((T*)out.p + voff(out, b, p, c), v + gsum);
     }
