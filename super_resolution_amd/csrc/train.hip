@@ -385,6 +385,63 @@ __global__ __launch_bounds__(256) void fbm_backward_kernel(long total_pix, long 
     }
 }
 
+// bf16 tensors with 8 | C <= 256: PC lanes per pixel (a power of two >= C / 8), 16 bytes (8 channels) per lane and tensor
+// -- an eighth of the memory instructions of the channel-per-lane kernel above, the per-pixel sums by shuffles inside
+// the PC-lane group.
+template <int PC>
+__global__ __launch_bounds__(256) void fbm_backward_vec_kernel(long total_pix, long npix, int C, View x, View l2, View l4, View l8,
+                                                               const float* __restrict__ gates, View da, View dx, View dl2,
+                                                               View dl4, View dl8, float* __restrict__ dlogits) {
+    constexpr int PPW = 64 / PC;  // pixels per wavefront
+    const int lane = threadIdx.x & 63, sub = lane & (PC - 1);
+    const long wave0 = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    const bool live = sub * 8 < C;
+    for (long pb = wave0 * PPW; pb < total_pix; pb += nwaves * PPW) {
+        const long pg = pb + lane / PC;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pg < total_pix) g = ((const float4*)gates)[pg];
+        if (live && pg < total_pix) {
+            const int b = (int)(pg / npix);
+            const long p = pg - (long)b * npix;
+            const float c1 = g.y - g.x, c2 = g.z - g.y, c3 = 1.0f - g.z;
+            const uint4 dv = *(const uint4*)((const bf16_t*)da.p + voff(da, b, p, sub * 8));
+            const uint4 xv = *(const uint4*)((const bf16_t*)x.p + voff(x, b, p, sub * 8));
+            const uint4 a2 = *(const uint4*)((const bf16_t*)l2.p + voff(l2, b, p, sub * 8));
+            const uint4 a4 = *(const uint4*)((const bf16_t*)l4.p + voff(l4, b, p, sub * 8));
+            const uint4 a8 = *(const uint4*)((const bf16_t*)l8.p + voff(l8, b, p, sub * 8));
+            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w}, w2[4] = {a2.x, a2.y, a2.z, a2.w},
+                           w4[4] = {a4.x, a4.y, a4.z, a4.w}, w8[4] = {a8.x, a8.y, a8.z, a8.w};
+            uint32_t o0[4], o2[4], o4[4], o8[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d0 = lo_f(dw[i]), d1 = hi_f(dw[i]);
+                s1 += d0 * (lo_f(xw[i]) - lo_f(w2[i])) + d1 * (hi_f(xw[i]) - hi_f(w2[i]));
+                s2 += d0 * (lo_f(w2[i]) - lo_f(w4[i])) + d1 * (hi_f(w2[i]) - hi_f(w4[i]));
+                s3 += d0 * (lo_f(w4[i]) - lo_f(w8[i])) + d1 * (hi_f(w4[i]) - hi_f(w8[i]));
+                o0[i] = pack2(g.x * d0, g.x * d1);
+                o2[i] = pack2(c1 * d0, c1 * d1);
+                o4[i] = pack2(c2 * d0, c2 * d1);
+                o8[i] = pack2(c3 * d0, c3 * d1);
+            }
+            *(uint4*)((bf16_t*)dx.p + voff(dx, b, p, sub * 8)) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+            *(uint4*)((bf16_t*)dl2.p + voff(dl2, b, p, sub * 8)) = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+            *(uint4*)((bf16_t*)dl4.p + voff(dl4, b, p, sub * 8)) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            *(uint4*)((bf16_t*)dl8.p + voff(dl8, b, p, sub * 8)) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+        }
+#pragma unroll
+        for (int m = PC / 2; m >= 1; m >>= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+            s3 += __shfl_xor(s3, m, 64);
+        }
+        if (sub == 0 && pg < total_pix)
+            ((float4*)dlogits)[pg] = make_float4(s1 * g.x * (1.0f - 0.5f * g.x), s2 * g.y * (1.0f - 0.5f * g.y),
+                                                 s3 * g.z * (1.0f - 0.5f * g.z), 0.f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // input-gradient assembly: dx = dx_direct + a2 + a4 + a8 + sum_{k,t} gw[k][c][t] dz_k[p - off(t)] + dpooled[b][c] / (H W)
 // lane <-> channel (the 27 gate weights of the channel stay in registers), a wavefront walks a run of pixels; the nine
@@ -571,7 +628,21 @@ extern "C" int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_vie
     fbm_backward_kernel<T><<<grid, 256, 0, st>>>(total, npix, C, to_view(x, npix), to_view(l2, npix), to_view(l4, npix),      \
                                                  to_view(l8, npix), gates, to_view(da, npix), to_view(dx, npix),                \
                                                  to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits)
-    if (dtype == SR_F32) SR_FB(float);
+    bool vec = dtype == SR_BF16 && C % 8 == 0 && C <= 256 && !g_wgrad_valu;  // (the hook keeps the scalar kernel: A/B test)
+    for (const sr_view* v : vs) vec = vec && wm_view_ok(to_view(*v, npix));
+    if (vec) {
+        const int pc = C <= 64 ? 8 : (C <= 128 ? 16 : 32);
+        const long waves = (total + 64 / pc - 1) / (64 / pc);
+        const int gridv = (int)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
+#define SR_FBV(PC_)                                                                                                             \
+    fbm_backward_vec_kernel<PC_><<<gridv, 256, 0, st>>>(total, npix, C, to_view(x, npix), to_view(l2, npix), to_view(l4, npix), \
+                                                        to_view(l8, npix), gates, to_view(da, npix), to_view(dx, npix),          \
+                                                        to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits)
+        if (pc == 8) SR_FBV(8);
+        else if (pc == 16) SR_FBV(16);
+        else SR_FBV(32);
+#undef SR_FBV
+    } else if (dtype == SR_F32) SR_FB(float);
     else SR_FB(bf16_t);
 #undef SR_FB
     SR_LAUNCH_CHECK();

@@ -146,6 +146,35 @@ def test_wgrad_mfma_matches_valu_kernel_bf16(sra, B, segs, cout, H, W, bands, up
     assert scale > 1.0 and err <= (2.0 ** -8 if bands else 1e-5) * scale, (err, scale)
 
 
+@pytest.mark.parametrize('B,Cc,H,W', [(2, 64, 9, 11), (1, 96, 16, 16), (3, 192, 7, 5), (2, 32, 8, 8), (1, 160, 5, 9)])
+def test_fbm_backward_vector_kernel_matches_scalar_kernel_bf16(sra, B, Cc, H, W):
+    """sr_fbm_backward on bf16 tensors: the 16-bytes-per-lane kernel (8 / 16 / 32 lanes per pixel) against the
+    channel-per-lane kernel -- the four branch gradients bit for bit, the gate-logit gradients to float32 summation order."""
+    from super_resolution_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(21)
+    bf = lambda: torch.randn(B, H, W, Cc, generator=g).to(torch.bfloat16).cuda().contiguous()
+    x, b2, b4, b8, da = bf(), bf(), bf(), bf(), bf()
+    gates = torch.cat([torch.rand(B, H, W, 3, generator=g) * 2, torch.zeros(B, H, W, 1)], 3).cuda().contiguous()
+    st = L.stream_ptr(torch.device('cuda:0'))
+    res = []
+    for scalar in (1, 0):
+        outs = [torch.full_like(x, float('nan')) for _ in range(4)]
+        dz = torch.full((B, H, W, 4), float('nan'), device='cuda')
+        lib.sr_debug_wgrad_valu(scalar)
+        try:
+            L.check(lib.sr_fbm_backward(1, B, H, W, L.view(x), L.view(b2), L.view(b4), L.view(b8), gates.data_ptr(), L.view(da),
+                                        L.view(outs[0]), L.view(outs[1]), L.view(outs[2]), L.view(outs[3]), dz.data_ptr(), st))
+            torch.cuda.synchronize()
+        finally:
+            lib.sr_debug_wgrad_valu(0)
+        res.append(([o.cpu() for o in outs], dz.cpu()))
+    (ro, rz), (go, gz) = res
+    for a, b in zip(ro, go):
+        assert torch.equal(a, b)
+    assert torch.isfinite(gz).all() and (gz - rz).abs().max().item() <= 1e-5 * max(1.0, rz.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------------- layers
 @pytest.mark.parametrize('tag,cin,cout,B,h,w,pseed', [('c64_32', 64, 32, 4, 20, 24, 100), ('c192_64', 192, 64, 2, 16, 12, 104)])
 def test_fdconv_train_mode_gradients_vs_reference(sra, golden_r2, tag, cin, cout, B, h, w, pseed):
