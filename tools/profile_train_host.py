@@ -23,6 +23,18 @@ def main():
     for _ in range(2):
         train.train_step(net, opt, wf, sr)
     torch.cuda.synchronize()
+    # the backward of the layers runs on autograd's device thread, which the profile of this thread does not see
+    prb = cProfile.Profile()
+    for cls in (train._FDConvFn, train._PlainConvFn):
+        orig = cls.backward
+
+        def wrapped(ctx, *a, _orig=orig):
+            prb.enable()
+            try:
+                return _orig(ctx, *a)
+            finally:
+                prb.disable()
+        cls.backward = staticmethod(wrapped)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(steps):
@@ -30,7 +42,9 @@ def main():
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr)
-    st.sort_stats('tottime').print_stats(45)
+    st.sort_stats('tottime').print_stats(25)
+    print('---- layer backward functions (autograd thread) ----')
+    pstats.Stats(prb).sort_stats('tottime').print_stats(40)
 
 
 if __name__ == '__main__':
