@@ -41,37 +41,51 @@ BN_EPS = 1e-5
 # ------------------------------------------------------------------------------------------------------------------
 # the small weight path as torch ops (backward glue)
 # ------------------------------------------------------------------------------------------------------------------
+def _group_onehot(m):
+    """(kernel_num, bins) float one-hot of the frequency-group id of every rfft2 bin: ka[b, G(r, c)] = ka @ onehot, a
+    matmul whose backward is a matmul (indexing with the group map goes back through an index_put)."""
+    gmap = m.group_map()
+    key = (gmap.data_ptr(), gmap.device)
+    hit = m._sr_cache.get('onehot')
+    if hit is None or hit[0] != key:
+        oh = F.one_hot(gmap.view(-1).long(), m.kernel_num).t().to(torch.float32).contiguous()
+        m._sr_cache['onehot'] = hit = (key, oh)
+    return hit[1]
+
+
 def dynamic_weight(pooled, m, training):
     """W_b (B, 9, Cout, Cin) of FDConv `m` from the pooled means (B, Cin): FDConv.py:643-652, 661-697.
 
     Same result as `sr_fdconv_weightgen`, built from differentiable torch ops; used only to back-propagate the weight
-    gradient into the KSM / spectrum parameters and the pooled means."""
+    gradient into the KSM / spectrum parameters and the pooled means.  A training step spends its host time here (349
+    layers, every op a launch and an autograd node), so the formulation keeps the op count low: fused batch norm, the
+    four attention heads as one linear + one sigmoid, the group lookup as a matmul, and every constant factor (the four
+    2 x sigmoid scalings, alpha and 2 / kernel_num) folded into the spectrum."""
     g, loc = m.KSM_Global, m.KSM_Local
     B, cin = pooled.shape
-    cout = m.out_channels
+    cout, kn = m.out_channels, m.kernel_num
     z = F.linear(pooled, g.fc.weight.flatten(1))
     if training:
-        mean, var = z.mean(0), z.var(0, unbiased=False)
+        z = F.batch_norm(z, None, None, g.bn.weight, g.bn.bias, True, 0.0, BN_EPS)
     else:
-        mean, var = g.bn.running_mean, g.bn.running_var
-    z = (z - mean) / torch.sqrt(var + BN_EPS) * g.bn.weight + g.bn.bias
-    a = g.relu.scale * torch.relu(z) ** 2 + g.relu.bias
-    head = lambda fc: F.linear(a, fc.weight.flatten(1), fc.bias)
-    ca = 2.0 * torch.sigmoid(head(g.channel_fc))                       # (B, Cin)
-    fa = 2.0 * torch.sigmoid(head(g.filter_fc))                        # (B, Cout)
-    sa = 2.0 * torch.sigmoid(head(g.spatial_fc))                       # (B, 9)
-    ka = torch.sigmoid(head(g.kernel_fc)) * (2.0 / m.kernel_num)       # (B, kn)
+        z = F.batch_norm(z, g.bn.running_mean, g.bn.running_var, g.bn.weight, g.bn.bias, False, 0.0, BN_EPS)
+    r = torch.relu(z)
+    a = torch.addcmul(g.relu.bias, r * g.relu.scale, r)                 # StarReLU: s relu(z)^2 + b
+    heads = (g.channel_fc, g.filter_fc, g.spatial_fc, g.kernel_fc)
+    hw = torch.cat([h.weight.flatten(1) for h in heads], 0)
+    hb = torch.cat([h.bias for h in heads], 0)
+    ca, fa, sa, ka = torch.sigmoid(F.linear(a, hw, hb)).split([cin, cout, 9, kn], 1)   # without their factors 2, 2, 2, 2 / kn
     ln = F.layer_norm(pooled, (cin,), loc.norm.weight, loc.norm.bias, 1e-5)
     k = loc.conv.kernel_size[0]
-    logit = F.conv1d(ln[:, None, :], loc.conv.weight, padding=(k - 1) // 2)        # (B, Cout*9, Cin)
-    hr = 2.0 * torch.sigmoid(logit).view(B, cout, 9, cin)                          # [b, o, tap, i]
+    hr = torch.sigmoid(F.conv1d(ln[:, None, :], loc.conv.weight, padding=(k - 1) // 2))  # (B, Cout*9, Cin), without its 2
     # spectrum scaled per frequency group and sample, inverse real 2-D DFT, (3Cout, 3Cin) -> [o, u, i, v]
-    spec = torch.view_as_complex(m.dft_weight[0].contiguous()) * float(m.alpha)    # (3Cout, 3Cin/2+1)
-    gmap = m.group_map().long()
-    per_bin = ka[:, gmap.view(-1)].view(B, *gmap.shape)                            # ka[b, G(r, c)]
-    adaptive = torch.fft.irfft2(spec[None] * per_bin, s=(3 * cout, 3 * cin))       # (B, 3Cout, 3Cin)
+    scale = 16.0 * float(m.alpha) * 2.0 / kn
+    spec = torch.view_as_complex(m.dft_weight[0]) * scale                                # (3Cout, 3Cin/2+1)
+    per_bin = (ka @ _group_onehot(m)).view(B, *spec.shape)                               # ka[b, G(r, c)]
+    adaptive = torch.fft.irfft2(spec * per_bin, s=(3 * cout, 3 * cin))                   # (B, 3Cout, 3Cin)
     adaptive = adaptive.view(B, cout, 3, cin, 3).permute(0, 2, 4, 1, 3).reshape(B, 9, cout, cin)
-    return sa.view(B, 9, 1, 1) * ca.view(B, 1, 1, cin) * fa.view(B, 1, cout, 1) * hr.permute(0, 2, 1, 3) * adaptive
+    mod = (sa[:, :, None] * fa[:, None, :])[:, :, :, None] * ca[:, None, None, :]        # (B, 9, Cout, Cin)
+    return mod * hr.view(B, cout, 9, cin).permute(0, 2, 1, 3) * adaptive
 
 
 _WEIGHT_PATH = ('dft_weight', 'KSM_Global.fc.weight', 'KSM_Global.bn.weight', 'KSM_Global.bn.bias', 'KSM_Global.relu.scale',
