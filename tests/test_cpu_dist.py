@@ -80,8 +80,20 @@ def _grad_worker(rank, world, port, q):
     dist.all_gather(gathered, mine)
     want = sum(gathered) / world
     got = torch.cat([p.grad.reshape(-1) for p in params])
+    ok = bool(torch.allclose(got, want, atol=1e-7))
+    # FlatAdam: the same exchange as ONE all-reduce over its flat gradient buffer (a parameter without a gradient on this
+    # rank enters as zeros); after the step both ranks hold the same parameters
+    from super_resolution_amd.train import FlatAdam
+    for p, g in zip(params, local):
+        p.grad = None if g is None else g.clone()
+    opt = FlatAdam(params, lr=1e-2)
+    opt.step()
+    ok = ok and bool(torch.allclose(opt.grad, want, atol=1e-7))
+    both = [torch.zeros_like(opt.flat) for _ in range(world)]
+    dist.all_gather(both, opt.flat)
+    ok = ok and bool(torch.equal(both[0], both[1]))
     # BatchNorm statistics stay local: the two ranks saw different halves of the batch
-    q.put((rank, bool(torch.allclose(got, want, atol=1e-7)), nb, net[1].running_mean.clone()))
+    q.put((rank, ok, nb, net[1].running_mean.clone()))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -275,3 +275,38 @@ def test_converter_matches_reference_converter(golden_r2):
     assert np.abs(d.numpy() - g['layer1.0.conv2.dft_weight']).max() < 1e-6
     coords, _ = get_fft2freq(96, 192, use_rfft=True)
     assert np.array_equal(coords.numpy(), g['idx_96_97'])
+
+
+def test_flat_adam_matches_torch_adam():
+    """train.FlatAdam (one flat buffer, one gather, five tensor ops) against torch.optim.Adam on the same gradients:
+    parameters after several steps, with and without weight decay / gradient clipping; parameter version counters move
+    (FDConv keys its cached spectral bases on them)."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from super_resolution_amd.train import FlatAdam
+    torch.manual_seed(3)
+    for wd, clip in ((0.0, None), (0.01, 0.5)):
+        a = nn.Sequential(nn.Linear(7, 5), nn.Tanh(), nn.Linear(5, 3), nn.Conv1d(3, 2, 1))
+        b = copy.deepcopy(a)
+        oa = torch.optim.Adam(a.parameters(), lr=1e-2, weight_decay=wd)
+        ob = FlatAdam(b.parameters(), lr=1e-2, weight_decay=wd)
+        v0 = [p._version for p in b.parameters()]
+        for step in range(5):
+            x = torch.randn(4, 7)
+            for net, opt in ((a, oa), (b, ob)):
+                opt.zero_grad()
+                y = net[:3](x)
+                loss = net[3](y[:, :, None]).pow(2).sum() + y.abs().sum()
+                loss.backward()
+                if opt is oa:
+                    if clip is not None:
+                        nn.utils.clip_grad_norm_(a.parameters(), clip)
+                    opt.step()
+                else:
+                    opt.step(clip_grad_norm=clip)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert (pa - pb).abs().max().item() < 2e-6, (wd, clip)
+        assert all(p._version > v for p, v in zip(b.parameters(), v0))
+        # the parameters are views of the flat buffer
+        assert all(p.data_ptr() >= ob.flat.data_ptr() for p in b.parameters())

@@ -329,6 +329,32 @@ def test_training_reduces_the_loss_and_scale2_runs(sra):
     assert net2.conv_first.weight.grad is not None and net2.conv_first.weight.grad.shape == (16, 12, 3, 3)
 
 
+def test_flat_adam_training_matches_torch_adam(sra):
+    """Three training steps with train.FlatAdam against three with torch.optim.Adam on a copy of the same FDConv network:
+    same losses and parameters.  The second and third step only agree if the layers rebuild their spectral bases from the
+    updated `dft_weight` -- the flat update must move the parameters' version counters, on which that cache is keyed."""
+    import copy
+    torch.manual_seed(0)
+    a = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 1, 32)).cuda()
+    b = copy.deepcopy(a)
+    oa = torch.optim.Adam(a.parameters(), lr=1e-3)
+    ob = sra.train.FlatAdam(b.parameters(), lr=1e-3)
+    wf = torch.from_numpy(gp.image_input((2, 1, 16, 16), seed=430)).cuda()
+    srt = torch.from_numpy(gp.image_input((2, 1, 64, 64), seed=431)).cuda()
+    la = [float(sra.train.train_step(a, oa, wf, srt)) for _ in range(3)]
+    lb = [float(sra.train.train_step(b, ob, wf, srt)) for _ in range(3)]
+    assert max(abs(x - y) for x, y in zip(la, lb)) <= 1e-5 * max(la), (la, lb)
+    assert la[1] != la[0]  # the parameters moved
+    # (the update rule itself is compared exactly on the CPU, tests/test_cpu_host.py: two GPU runs differ in the order of
+    # their float32 atomics, and Adam's first steps turn a sign flip of a near-zero gradient into 2 lr)
+    # no stale cache: a network built afresh from b's state_dict computes what b computes
+    fresh = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 1, 32)).cuda()
+    fresh.load_state_dict(b.state_dict())
+    with torch.no_grad():
+        yb, yf = b.eval()(wf), fresh.eval()(wf)
+    assert torch.equal(yb, yf)
+
+
 def test_mixed_precision_training_step_tracks_the_float32_step(sra):
     """bf16 compute (net.compute_dtype): MFMA convolution forward / operand gradient with split weights, MFMA low-pass, bf16
     activations and activation gradients; parameters and weight gradients float32.  No reference counterpart (the owner
