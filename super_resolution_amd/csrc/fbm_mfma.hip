@@ -837,8 +837,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     auto grid_for = [&](long items, int G) { return (int)std::min<long>((long)NB * ((items + G - 1) / G), g_mfma_cus); };
     const int nh_real = pl->mf_nhk[0];
     // wide instances: K up to 544 in the analysis (34 k-steps), up to 272 in the synthesis (17 k-steps)
-    const bool wide_aw = W > 512, wide_ah = H > 512, wide_s = pl->mf_ld_qw > 256 || pl->mf_ld_ph > 256;
-    auto lds_ana = [](bool wide) { return 2 * (wide ? 34 : 32) * 16 * 128; };
+    const bool wide_s = pl->mf_ld_qw > 256 || pl->mf_ld_ph > 256;
     const int lds_syn = 2 * (wide_s ? 17 : 16) * 16 * 256 + WIN_B;
 
     AnaArgs a1{};  // T = x Qw
@@ -858,15 +857,23 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     // fp16 range of the intermediates: an orthonormal coefficient can reach sqrt(W) (sqrt(H W)) times the largest
     // activation, so T and U are kept as T / 4, U / 4 and S as S / 64 (no overflow below |x| ~ 8000; the epilogues saturate)
     a1.scale = 0.25f;
+    // k-steps of the instance: the k loop always runs all of them (see mf_analysis), so short transforms -- the 64 x 64
+    // crops of a training step, small inference inputs -- take instances of 4 or 8 steps instead of multiplying zeros
+#define SR_ANA(FV, KS_, ARGS, ITEMS)                                                                          \
+    do {                                                                                                      \
+        SR_LDS_ATTR(2 * KS_ * 16 * 128, mf_analysis<FV, KS_>);                                                \
+        mf_analysis<FV, KS_><<<grid_for(ITEMS, 2), THREADS, 2 * KS_ * 16 * 128, st>>>(ARGS);                  \
+    } while (0)
+#define SR_ANA_BY_K(FV, K_, ARGS, ITEMS)                  \
+    do {                                                  \
+        if ((K_) <= 64) SR_ANA(FV, 4, ARGS, ITEMS);       \
+        else if ((K_) <= 128) SR_ANA(FV, 8, ARGS, ITEMS); \
+        else if ((K_) <= 512) SR_ANA(FV, 32, ARGS, ITEMS);\
+        else SR_ANA(FV, 34, ARGS, ITEMS);                 \
+    } while (0)
     for (int t0 = 0; t0 < jw / 32; t0 += 8) {  // more than 8 basis tiles: the data is streamed once per 8 tiles
         a1.tile0 = t0;
-        if (wide_aw) {
-            SR_LDS_ATTR(lds_ana(true), mf_analysis<true, 34>);
-            mf_analysis<true, 34><<<grid_for(H, 2), THREADS, lds_ana(true), st>>>(a1);
-        } else {
-            SR_LDS_ATTR(lds_ana(false), mf_analysis<true, 32>);
-            mf_analysis<true, 32><<<grid_for(H, 2), THREADS, lds_ana(false), st>>>(a1);
-        }
+        SR_ANA_BY_K(true, W, a1, H);
         SR_LAUNCH_CHECK();
     }
 
@@ -891,13 +898,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         a2.tile0 = t0;
         a2.pooled = t0 == 0 ? pooled : nullptr;
         a2.pooled_ld = pooled_ld;
-        if (wide_ah) {
-            SR_LDS_ATTR(lds_ana(true), mf_analysis<false, 34>);
-            mf_analysis<false, 34><<<grid_for(a2.nitems, 2), THREADS, lds_ana(true), st>>>(a2);
-        } else {
-            SR_LDS_ATTR(lds_ana(false), mf_analysis<false, 32>);
-            mf_analysis<false, 32><<<grid_for(a2.nitems, 2), THREADS, lds_ana(false), st>>>(a2);
-        }
+        SR_ANA_BY_K(false, H, a2, a2.nitems);
         SR_LAUNCH_CHECK();
     }
 
