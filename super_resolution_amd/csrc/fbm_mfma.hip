@@ -50,7 +50,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s4;
 
 constexpr int THREADS = 512;
-constexpr int IMG_B = 64 * 1024;  // one staged data image: K rows x G items x 32 channels x fp16
+// (one staged data image = K rows x G items x 32 channels x fp16: 64 KiB at 32 x 16 rows of 128 B or 16 x 16 rows of 256 B)
 // Basis tables are stored fragment-major: the 64 x 8 halfs one wave needs for (row tile nt, k-step ks) are 1 KiB
 // contiguous (lane = 32 * (k / 8 % 2) + row % 32).
 __host__ __device__ inline size_t frag_index(int row, int k, int nks) {
@@ -529,8 +529,11 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
 // coefficients in rows 128..255.  The column w = W/2 (where every sin vanishes) is one more basis tile, run by wave 0.
 // Basis table: tiles 0 .. W/64 - 1 = columns w (k-steps 0..7 cos, 8..15 sin), tile W/64 = column W/2 in its row 0.
 // ---------------------------------------------------------------------------------------------------------------
+// KH = k-steps per half (8: up to 128 cos + 128 sin coefficients; 4 / 2 / 1 for short rows, whose staged image, loads and
+// basis registers shrink with it -- at W = 64 the 8-step instance moved 64 KiB per item group for 2 KiB of coefficients).
+template <int KH>
 __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
-    constexpr int G = 4, ROWB = 256, KH = 8, SIN0 = 128;
+    constexpr int G = 4, ROWB = 256, SIN0 = 16 * KH, IMG_W = 32 * KH * ROWB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -540,11 +543,11 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KH; ++ks) {
         bE[ks] = *(const half8*)(a.basis + ((size_t)(tw * 16 + ks) * 64 + lane) * 8);
-        bO[ks] = *(const half8*)(a.basis + ((size_t)(tw * 16 + KH + ks) * 64 + lane) * 8);
+        bO[ks] = *(const half8*)(a.basis + ((size_t)(tw * 16 + 8 + ks) * 64 + lane) * 8);  // table: 8 cos + 8 sin steps per tile
         bN[ks] = *(const half8*)(a.basis + ((size_t)(NTh * 16 + ks) * 64 + lane) * 8);
     }
     const int gpb = (a.nitems[0] + G - 1) / G, ngroups = a.NB * gpb;
-    auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[8]) {
+    auto fetch = [&](int tl, int grp, int band, uint4 (&pre)[KH]) {
         const int ch = tl & 15, r0 = tl >> 4, oct = ch & 3;
         const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
         const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
@@ -554,14 +557,14 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
         const int sk = sel3(band, a.src_k[0], a.src_k[1], a.src_k[2]);
         (void)sk;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre[i] = *(const uint4*)u_addr(sb, min(r0 + 32 * i, K - 1), a.nitems[0]);
+        for (int i = 0; i < KH; ++i) pre[i] = *(const uint4*)u_addr(sb, min(r0 + 32 * i, K - 1), a.nitems[0]);
     };
-    // coefficient j = r0 + 32 i -> image row (j >> 1) + 128 (j & 1); all 256 rows are written (zeros from j = K on)
-    auto stash = [&](int tl, const uint4 (&pre)[8], char* img, int band) {
+    // coefficient j = r0 + 32 i -> image row (j >> 1) + SIN0 (j & 1); all 32 KH rows are written (zeros from j = K on)
+    auto stash = [&](int tl, const uint4 (&pre)[KH], char* img, int band) {
         const int ch = tl & 15, r0 = tl >> 4;
         const int K = sel3(band, a.K[0], a.K[1], a.K[2]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < KH; ++i) {
             const int row = (r0 >> 1) + 16 * i + (r0 & 1) * SIN0;
             *(uint4*)(img + img_off<G>(row, ch)) = r0 + 32 * i < K ? pre[i] : make_uint4(0u, 0u, 0u, 0u);
         }
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
 
     int grp = blockIdx.x, band = a.bfirst;
     if (grp >= ngroups) return;
-    uint4 pre[8];
+    uint4 pre[KH];
     fetch(tid, grp, band, pre);
     stash(tid, pre, lds, band);
     __syncthreads();
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
         const bool more = ngrp < ngroups;
         fetch(fresh_tid(wave), more ? ngrp : grp, more ? nband : band, pre);  // unconditional (see mf_analysis)
         asm volatile("" ::: "memory");
-        const char* img = lds + (it & 1) * IMG_B;
+        const char* img = lds + (it & 1) * IMG_W;
         const int bcg = grp / gpb, i0 = (grp - bcg * gpb) * G;
         const int b = bcg / a.CG, cg = bcg - b * a.CG;
         const int hk = lane >> 5;
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis_wf(SynArgs a) {
             }
             if (g == 1) {
                 // stage the next image before the first store of this group goes out (see mf_analysis)
-                if (more) stash(fresh_tid(wave), pre, lds + ((it + 1) & 1) * IMG_B, nband);
+                if (more) stash(fresh_tid(wave), pre, lds + ((it + 1) & 1) * IMG_W, nband);
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) {
@@ -929,13 +932,19 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     s3.nks_tab = pl->mf_ld_ph / 16;
     for (int t0 = 0; t0 < s3.M / 32; t0 += 16) {  // more than 16 basis tiles: S is streamed once per 16 tiles
         s3.tile0 = t0;
-        if (wide_s) {
-            SR_LDS_ATTR(lds_syn, mf_synthesis<true, 17>);
-            mf_synthesis<true, 17><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, lds_syn, st>>>(s3);
-        } else {
-            SR_LDS_ATTR(lds_syn, mf_synthesis<true, 16>);
-            mf_synthesis<true, 16><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, lds_syn, st>>>(s3);
-        }
+        // k-steps the instance must hold: the coefficient rows and every band's main + window steps
+        int need = (nh_real + 15) / 16;
+        for (int k = 0; k < 3; ++k) need = std::max(need, pl->mf_ksm[k] + pl->mf_nwin[k]);
+#define SR_SYNH(KS_)                                                                                              \
+    do {                                                                                                          \
+        SR_LDS_ATTR(2 * KS_ * 16 * 256 + WIN_B, mf_synthesis<true, KS_>);                                         \
+        mf_synthesis<true, KS_><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, 2 * KS_ * 16 * 256 + WIN_B, st>>>(s3); \
+    } while (0)
+        if (wide_s) SR_SYNH(17);
+        else if (need <= 4) SR_SYNH(4);
+        else if (need <= 8) SR_SYNH(8);
+        else SR_SYNH(16);
+#undef SR_SYNH
         SR_LAUNCH_CHECK();
     }
 
@@ -963,8 +972,17 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         for (int k = 0; k < 3; ++k) s4.ksm[k] = (pl->mf_nw[k] / 2 + 15) / 16;  // k-steps per half (cos / sin)
         s4.basis = (const h16*)pl->mf_qwf;
         s4.nks_tab = 16;
-        SR_LDS_ATTR(2 * IMG_B, mf_synthesis_wf);
-        mf_synthesis_wf<<<grid_for(H, 4), THREADS, 2 * IMG_B, st>>>(s4);
+        const int kh = s4.ksm[0];  // k-steps per half of the widest band
+#define SR_WF(KH_)                                                                              \
+    do {                                                                                        \
+        SR_LDS_ATTR(2 * 32 * KH_ * 256, mf_synthesis_wf<KH_>);                                  \
+        mf_synthesis_wf<KH_><<<grid_for(H, 4), THREADS, 2 * 32 * KH_ * 256, st>>>(s4);          \
+    } while (0)
+        if (kh <= 1) SR_WF(1);
+        else if (kh <= 2) SR_WF(2);
+        else if (kh <= 4) SR_WF(4);
+        else SR_WF(8);
+#undef SR_WF
         SR_LAUNCH_CHECK();
     } else {
         s4.basis = (const h16*)pl->mf_qw;
