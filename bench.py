@@ -428,7 +428,7 @@ def run_train(args, world, rank, dev, dist):
                                '(BASELINE.json configs[3], L1 term of the owner script)'
                                % (B, hr, hr, lr_side, lr_side, 'bf16 activations on MFMA, float32 parameters / weight gradients / Adam' if mixed else 'float32'),
                    'global_batch': world * B, 'samples_per_s': world * B / step_s,
-                   'parallelism': 'data parallel x%d, bucketed gradient all-reduce of %.1f M parameters (local BatchNorm statistics)' % (world, nparam / 1e6),
+                   'parallelism': 'data parallel x%d, one all-reduce over the flat %.1f M-parameter gradient buffer per step (local BatchNorm statistics)' % (world, nparam / 1e6),
                    'loss_first_last': [losses[0], losses[-1]], 'loss_finite': bool(np.isfinite(losses).all()),
                    'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9},
         'roofline': {'bound': 'mfma', 'kernel': 'conv forward + operand gradient + weight gradient: on the matrix cores in bf16 mode (float32 accumulation), VALU kernels in f32 mode',

@@ -11,6 +11,8 @@
 //                              (direct branch + the three low-passed band branches + transposed gate conv + pooled mean)
 // The box low-pass is self-adjoint (a real symmetric mask between a unitary transform pair), so the band branches go
 // back through sr_fbm_lowpass itself.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sr {
@@ -282,7 +284,8 @@ static int wgrad_mfma_launch(const Concat& c, int B, int H, int W, const float* 
     const size_t lds = (size_t)(WM_A_BYTES + mt * WM_D_BYTES) > (size_t)mt * WM_RED_BYTES ? (size_t)(WM_A_BYTES + mt * WM_D_BYTES)
                                                                                          : (size_t)mt * WM_RED_BYTES;
     // about 1024 workgroups per launch over all segments: fills the chip, few atomic rounds per element
-    int spb = (int)(((long)nstrips * (cin / 32) * B + 1023) / 1024);
+    static const int target_wgs = getenv("SR_AMD_WGRAD_WGS") && atoi(getenv("SR_AMD_WGRAD_WGS")) > 0 ? atoi(getenv("SR_AMD_WGRAD_WGS")) : 1024;
+    int spb = (int)(((long)nstrips * (cin / 32) * B + target_wgs - 1) / target_wgs);
     if (spb < 1) spb = 1;
     for (int s = 0; s < c.nseg; ++s) {
         WmSeg sg;
