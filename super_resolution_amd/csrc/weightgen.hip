@@ -16,22 +16,47 @@ constexpr int KN = 4;    // kernel_num (frequency groups), owner scripts use the
 constexpr int ATT = 16;  // attention channels: max(int(cin*0.0625), 16) = 16 for cin < 272
 
 // ---- basis: stage A  Z[g][y][c] = sum_r [G[r][c]==g] D[r][c] e^{+2 pi i r y / N1} ------------
+// The phase factors e^{2 pi i k / N} come from a per-workgroup LDS table (same sincospi values as evaluating them per
+// term, which cost ~100 fp64 instructions each: 390 -> tens of microseconds for the 192 -> 64 layer, paid once per weight
+// update, i.e. per training step); N beyond the table falls back to evaluating per term.
+constexpr int BASIS_TW = 2048;
+__device__ __forceinline__ void fill_phase_table(double2* tw, int N) {
+    if (N <= BASIS_TW) {
+        for (int k = threadIdx.x; k < N; k += blockDim.x) {
+            double s, co;
+            sincospi(2.0 * k / N, &s, &co);
+            tw[k] = make_double2(co, s);
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double2 phase(const double2* tw, int ph, int N) {
+    if (N <= BASIS_TW) return tw[ph];
+    double s, co;
+    sincospi(2.0 * ph / N, &s, &co);
+    return make_double2(co, s);
+}
+
 __global__ void basis_stage_a(const float* __restrict__ dft, const uint8_t* __restrict__ gmap, int N1, int n2h,
                               double2* __restrict__ Z) {
+    __shared__ double2 tw[BASIS_TW];
+    fill_phase_table(tw, N1);
     const long total = (long)KN * N1 * n2h;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % n2h);
         const int y = (int)((i / n2h) % N1);
         const int g = (int)(i / ((long)n2h * N1));
         double re = 0.0, im = 0.0;
+        int ph = 0;  // (r * y) mod N1
         for (int r = 0; r < N1; ++r) {
-            if (gmap[(long)r * n2h + c] != g) continue;
-            const double dr = dft[((long)r * n2h + c) * 2], di = dft[((long)r * n2h + c) * 2 + 1];
-            const int ph = (int)(((long)r * y) % N1);
-            double s, co;
-            sincospi(2.0 * ph / N1, &s, &co);
-            re += dr * co - di * s;
-            im += dr * s + di * co;
+            if (gmap[(long)r * n2h + c] == g) {
+                const double dr = dft[((long)r * n2h + c) * 2], di = dft[((long)r * n2h + c) * 2 + 1];
+                const double2 w = phase(tw, ph, N1);
+                re += dr * w.x - di * w.y;
+                im += dr * w.y + di * w.x;
+            }
+            ph += y;
+            if (ph >= N1) ph -= N1;
         }
         Z[i] = make_double2(re, im);
     }
@@ -41,6 +66,8 @@ __global__ void basis_stage_a(const float* __restrict__ dft, const uint8_t* __re
 // C2R semantics: only the real part of the self-conjugate columns contributes, weight 1; others 2.
 __global__ void basis_stage_b(const double2* __restrict__ Z, float alpha, int cout, int cin, float* __restrict__ basis) {
     const int N1 = 3 * cout, N2 = 3 * cin, n2h = N2 / 2 + 1;
+    __shared__ double2 tw[BASIS_TW];
+    fill_phase_table(tw, N2);
     const long total = (long)KN * N1 * N2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int x = (int)(i % N2);
@@ -48,12 +75,13 @@ __global__ void basis_stage_b(const double2* __restrict__ Z, float alpha, int co
         const int g = (int)(i / ((long)N2 * N1));
         const double2* z = Z + ((long)g * N1 + y) * n2h;
         double acc = 0.0;
+        int ph = 0;  // (c * x) mod N2
         for (int c = 0; c < n2h; ++c) {
-            const int ph = (int)(((long)c * x) % N2);
-            double s, co;
-            sincospi(2.0 * ph / N2, &s, &co);
+            const double2 w = phase(tw, ph, N2);
             const double wgt = (c == 0 || (N2 % 2 == 0 && c == N2 / 2)) ? 1.0 : 2.0;
-            acc += wgt * (z[c].x * co - z[c].y * s);
+            acc += wgt * (z[c].x * w.x - z[c].y * w.y);
+            ph += x;
+            if (ph >= N2) ph -= N2;
         }
         acc *= (double)alpha / ((double)N1 * (double)N2);
         // M[y = o*3+u][x = ci*3+v] -> basis[g][o][ci][u*3+v]   (reshape+permute at FDConv.py:683-684)
