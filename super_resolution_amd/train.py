@@ -53,6 +53,35 @@ def _group_onehot(m):
     return hit[1]
 
 
+class _GroupLookup(torch.autograd.Function):
+    """per_bin[b, j] = ka[b, G(j)] as a matmul with the one-hot map; its gradient wrt ka is a per-group sum, taken over the
+    bins sorted by group (the matmul form, (B x bins) @ (bins x kernel_num), is a 55k-deep skinny GEMM: 63 us)."""
+
+    @staticmethod
+    def forward(ctx, ka, onehot, order):
+        ctx.save_for_backward(order)
+        ctx.kn = onehot.shape[0]
+        return ka @ onehot
+
+    @staticmethod
+    def backward(ctx, g):
+        (order,) = ctx.saved_tensors
+        return g.index_select(1, order).view(g.shape[0], ctx.kn, -1).sum(2), None, None
+
+
+def _group_order(m):
+    """bin indices sorted by group id (every group holds the same number of bins: FDConv.py:604-631), cached."""
+    gmap = m.group_map()
+    key = (gmap.data_ptr(), gmap.device)
+    hit = m._sr_cache.get('order')
+    if hit is None or hit[0] != key:
+        flat = gmap.view(-1).long()
+        if not bool((torch.bincount(flat, minlength=m.kernel_num) == flat.numel() // m.kernel_num).all()):
+            raise ValueError('FDConv: frequency groups of unequal size')
+        m._sr_cache['order'] = hit = (key, torch.sort(flat, stable=True).indices)
+    return hit[1]
+
+
 def dynamic_weight(pooled, m, training):
     """W_b (B, 9, Cout, Cin) of FDConv `m` from the pooled means (B, Cin): FDConv.py:643-652, 661-697.
 
@@ -76,16 +105,19 @@ def dynamic_weight(pooled, m, training):
     hb = torch.cat([h.bias for h in heads], 0)
     ca, fa, sa, ka = torch.sigmoid(F.linear(a, hw, hb)).split([cin, cout, 9, kn], 1)   # without their factors 2, 2, 2, 2 / kn
     ln = F.layer_norm(pooled, (cin,), loc.norm.weight, loc.norm.bias, 1e-5)
+    # KSM_Local's k-tap conv along the channel axis as a matmul over unfolded windows (a 1 -> Cout*9 channel conv1d of length
+    # Cin lands on MIOpen's naive kernels in backward: 0.5 ms per call)
     k = loc.conv.kernel_size[0]
-    hr = torch.sigmoid(F.conv1d(ln[:, None, :], loc.conv.weight, padding=(k - 1) // 2))  # (B, Cout*9, Cin), without its 2
+    lnu = F.pad(ln, ((k - 1) // 2, (k - 1) // 2)).unfold(1, k, 1)                        # (B, Cin, k)
+    hr = torch.sigmoid(lnu @ loc.conv.weight.view(cout * 9, k).t())                      # (B, Cin, Cout*9), without its 2
     # spectrum scaled per frequency group and sample, inverse real 2-D DFT, (3Cout, 3Cin) -> [o, u, i, v]
     scale = 16.0 * float(m.alpha) * 2.0 / kn
     spec = torch.view_as_complex(m.dft_weight[0]) * scale                                # (3Cout, 3Cin/2+1)
-    per_bin = (ka @ _group_onehot(m)).view(B, *spec.shape)                               # ka[b, G(r, c)]
+    per_bin = _GroupLookup.apply(ka, _group_onehot(m), _group_order(m)).view(B, *spec.shape)  # ka[b, G(r, c)]
     adaptive = torch.fft.irfft2(spec * per_bin, s=(3 * cout, 3 * cin))                   # (B, 3Cout, 3Cin)
     adaptive = adaptive.view(B, cout, 3, cin, 3).permute(0, 2, 4, 1, 3).reshape(B, 9, cout, cin)
     mod = (sa[:, :, None] * fa[:, None, :])[:, :, :, None] * ca[:, None, None, :]        # (B, 9, Cout, Cin)
-    return mod * hr.view(B, cout, 9, cin).permute(0, 2, 1, 3) * adaptive
+    return mod * hr.view(B, cin, cout, 9).permute(0, 3, 2, 1) * adaptive
 
 
 _WEIGHT_PATH = ('dft_weight', 'KSM_Global.fc.weight', 'KSM_Global.bn.weight', 'KSM_Global.bn.bias', 'KSM_Global.relu.scale',

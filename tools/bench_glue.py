@@ -1,0 +1,79 @@
+"""A/B of the weight-path glue (train.dynamic_weight forward + autograd.grad) on one layer shape, in one process:
+GPU time (events) and host time per call.   usage: python tools/bench_glue.py [cin cout B]"""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import super_resolution_amd as sra  # noqa: E402
+from super_resolution_amd import train as T  # noqa: E402
+
+
+def variant(name):
+    """Returns a dynamic_weight with one piece swapped back to its earlier formulation."""
+    if name == 'current':
+        return T.dynamic_weight
+    src = T.dynamic_weight
+
+    def fn(pooled, m, training):
+        if name == 'conv1d':
+            orig_pad, orig_sig = F.pad, None
+            # earlier formulation of KSM_Local: conv1d along the channel axis
+            g, loc = m.KSM_Global, m.KSM_Local
+            B, cin = pooled.shape
+            cout, kn = m.out_channels, m.kernel_num
+            z = F.batch_norm(F.linear(pooled, g.fc.weight.flatten(1)), None, None, g.bn.weight, g.bn.bias, True, 0.0, T.BN_EPS)
+            r = torch.relu(z)
+            a = torch.addcmul(g.relu.bias, r * g.relu.scale, r)
+            heads = (g.channel_fc, g.filter_fc, g.spatial_fc, g.kernel_fc)
+            hw = torch.cat([h.weight.flatten(1) for h in heads], 0)
+            hb = torch.cat([h.bias for h in heads], 0)
+            ca, fa, sa, ka = torch.sigmoid(F.linear(a, hw, hb)).split([cin, cout, 9, kn], 1)
+            ln = F.layer_norm(pooled, (cin,), loc.norm.weight, loc.norm.bias, 1e-5)
+            k = loc.conv.kernel_size[0]
+            hr = torch.sigmoid(F.conv1d(ln[:, None, :], loc.conv.weight, padding=(k - 1) // 2))
+            spec = torch.view_as_complex(m.dft_weight[0]) * (16.0 * float(m.alpha) * 2.0 / kn)
+            per_bin = T._GroupLookup.apply(ka, T._group_onehot(m), T._group_order(m)).view(B, *spec.shape)
+            ad = torch.fft.irfft2(spec * per_bin, s=(3 * cout, 3 * cin))
+            ad = ad.view(B, cout, 3, cin, 3).permute(0, 2, 4, 1, 3).reshape(B, 9, cout, cin)
+            mod = (sa[:, :, None] * fa[:, None, :])[:, :, :, None] * ca[:, None, None, :]
+            return mod * hr.view(B, cout, 9, cin).permute(0, 2, 1, 3) * ad
+        raise ValueError(name)
+    return fn
+
+
+def main():
+    cin, cout, B = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (192, 64, 32)
+    torch.manual_seed(0)
+    m = sra.FDConv(cin, cout, 3, padding=1).cuda().train()
+    pooled = torch.randn(B, cin, device='cuda')
+    dw = torch.randn(B, 9, cout, cin, device='cuda')
+    params = dict(m.named_parameters())
+    wp = [params[n] for n in T._WEIGHT_PATH]
+    for name in ('current', 'conv1d', 'current', 'conv1d'):
+        fn = variant(name)
+
+        def once():
+            pl = pooled.detach().requires_grad_(True)
+            with torch.enable_grad():
+                w = fn(pl, m, True)
+                return torch.autograd.grad(w, [pl] + wp, dw, allow_unused=True)
+        for _ in range(5):
+            once()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(50):
+            once()
+        e1.record()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print('%-8s %dx%d B=%d: host %.3f ms per call, device span %.3f ms per call' % (name, cin, cout, B, (t1 - t0) * 20, e0.elapsed_time(e1) / 50))
+
+
+if __name__ == '__main__':
+    main()
