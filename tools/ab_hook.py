@@ -21,6 +21,7 @@ from super_resolution_amd import _lib as L  # noqa: E402
 def main():
     hook = sys.argv[1]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    on_value = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # value passed for the 'on' leg
     dev = torch.device('cuda:0')
     net, _ = bench.build_model(dev)
     x = bench.synthetic_batch(16, 512, 512, dev).to(torch.bfloat16)
@@ -30,7 +31,7 @@ def main():
         net(x)
         for rd in range(rounds):
             for on in (0, 1):
-                fn(on)
+                fn(on * on_value)
                 net(x)
                 torch.cuda.synchronize()
                 net.profile(2)
