@@ -489,6 +489,74 @@ __global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, in
     }
 }
 
+// bf16 tensors with 8 | C <= 256: lane <-> (pixel of the run, 8-channel group), 16 bytes per lane and tensor; the 27 gate
+// weights of every channel are staged once per workgroup in LDS as [tap][gate][C] floats and read as float4 pairs.
+template <int PC>  // lanes per pixel (a power of two >= C / 8)
+__global__ __launch_bounds__(256) void input_grad_vec_kernel(int B, int H, int W, int C, const float* __restrict__ dz,
+                                                             sr_layer_params lp, View dxd, View a2, View a4, View a8,
+                                                             const float* __restrict__ dpooled, int dpooled_ld, View out,
+                                                             int pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float gw_lds[];  // [9][3][C]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) {
+        const int c = i % C, k = (i / C) % 3, t = i / (3 * C);
+        gw_lds[i] = lp.gate_w[k][c * 9 + t];
+    }
+    __syncthreads();
+    const long npix = (long)H * W, total = (long)B * npix;
+    const float inv = 1.0f / (float)npix;
+    constexpr int PPI = 256 / PC;  // pixels per iteration of the workgroup
+    const int sub = threadIdx.x & (PC - 1), slot = threadIdx.x / PC;
+    const bool live = sub * 8 < C;
+    const int c0 = live ? sub * 8 : 0;
+    const long q0 = (long)blockIdx.x * pix_per_block, q1 = min(total, q0 + pix_per_block);
+#pragma unroll 2
+    for (long pb = q0; pb < q1; pb += PPI) {
+        const long pg = pb + slot;
+        if (pg >= q1 || !live) continue;
+        const int b = (int)(pg / npix);
+        const long p = pg - (long)b * npix;
+        const int h = (int)(p / W), w = (int)(p - (long)h * W);
+        const uint4 v0 = *(const uint4*)((const bf16_t*)dxd.p + voff(dxd, b, p, c0));
+        const uint4 v2 = *(const uint4*)((const bf16_t*)a2.p + voff(a2, b, p, c0));
+        const uint4 v4 = *(const uint4*)((const bf16_t*)a4.p + voff(a4, b, p, c0));
+        const uint4 v8 = *(const uint4*)((const bf16_t*)a8.p + voff(a8, b, p, c0));
+        const uint32_t w0[4] = {v0.x, v0.y, v0.z, v0.w}, w2[4] = {v2.x, v2.y, v2.z, v2.w}, w4[4] = {v4.x, v4.y, v4.z, v4.w},
+                       w8[4] = {v8.x, v8.y, v8.z, v8.w};
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] = lo_f(w0[i]) + lo_f(w2[i]) + lo_f(w4[i]) + lo_f(w8[i]);
+            acc[2 * i + 1] = hi_f(w0[i]) + hi_f(w2[i]) + hi_f(w4[i]) + hi_f(w8[i]);
+        }
+        if (dpooled) {
+            const float4 d0 = *(const float4*)(dpooled + (long)b * dpooled_ld + c0), d1 = *(const float4*)(dpooled + (long)b * dpooled_ld + c0 + 4);
+            acc[0] += d0.x * inv; acc[1] += d0.y * inv; acc[2] += d0.z * inv; acc[3] += d0.w * inv;
+            acc[4] += d1.x * inv; acc[5] += d1.y * inv; acc[6] += d1.z * inv; acc[7] += d1.w * inv;
+        }
+        float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            float4 d = ((const float4*)dz)[(long)b * npix + (long)min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1)];
+            if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float dk[3] = {d.x, d.y, d.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 ga = *(const float4*)(gw_lds + (t * 3 + k) * C + c0), gb = *(const float4*)(gw_lds + (t * 3 + k) * C + c0 + 4);
+                gs[0] += ga.x * dk[k]; gs[1] += ga.y * dk[k]; gs[2] += ga.z * dk[k]; gs[3] += ga.w * dk[k];
+                gs[4] += gb.x * dk[k]; gs[5] += gb.y * dk[k]; gs[6] += gb.z * dk[k]; gs[7] += gb.w * dk[k];
+            }
+        }
+        uint4 o;
+        o.x = pack2(acc[0] + gs[0], acc[1] + gs[1]);
+        o.y = pack2(acc[2] + gs[2], acc[3] + gs[3]);
+        o.z = pack2(acc[4] + gs[4], acc[5] + gs[5]);
+        o.w = pack2(acc[6] + gs[6], acc[7] + gs[7]);
+        *(uint4*)((bf16_t*)out.p + voff(out, b, p, c0)) = o;
+    }
+}
+
 // gate-conv weight / bias gradients: workgroup = 64 channels x a run of pixels; lane <-> channel, the 4 waves take
 // interleaved pixels; dgw[k][c][t] += x[q][c] * dz_k[q - off(t)].  The body is branch-free (clamped neighbour address,
 // validity as a factor) and unrolled four pixels deep so that the loads of several pixels are in flight: the kernel is a
@@ -681,7 +749,27 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
             SR_LAUNCH_CHECK();                                                                                                   \
         }                                                                                                                        \
     } while (0)
-    if (dtype == SR_F32) SR_GB(float);
+    bool vec = dtype == SR_BF16 && C % 8 == 0 && C <= 256 && !g_wgrad_valu && (!dpooled || (dpooled_ld % 4 == 0 && (uintptr_t)dpooled % 16 == 0));
+    const sr_view* vv[5] = {&dx_direct, &a2, &a4, &a8, &dx_out};
+    for (const sr_view* v : vv) vec = vec && wm_view_ok(to_view(*v, npix));
+    if (vec) {
+        const int pc = C <= 64 ? 8 : (C <= 128 ? 16 : 32);
+        const int ppbv = 1024;  // pixels per workgroup: the 27 x C gate weights are staged once for them
+        const size_t ldsv = (size_t)27 * C * sizeof(float);
+#define SR_IGV(PC_)                                                                                                              \
+    input_grad_vec_kernel<PC_><<<cdiv(total, ppbv), 256, ldsv, st>>>(B, H, W, C, dlogits, *lp, to_view(dx_direct, npix),         \
+                                                                     to_view(a2, npix), to_view(a4, npix), to_view(a8, npix),    \
+                                                                     dpooled, dpooled_ld, to_view(dx_out, npix), ppbv)
+        if (pc == 8) SR_IGV(8);
+        else if (pc == 16) SR_IGV(16);
+        else SR_IGV(32);
+#undef SR_IGV
+        SR_LAUNCH_CHECK();
+        if (dgate_w) {
+            gate_wgrad_kernel<bf16_t><<<g2, 256, 0, st>>>(B, H, W, C, to_view(x, npix), dlogits, dgate_w, dgate_b, ppb);
+            SR_LAUNCH_CHECK();
+        }
+    } else if (dtype == SR_F32) SR_GB(float);
     else SR_GB(bf16_t);
 #undef SR_GB
     return SR_OK;

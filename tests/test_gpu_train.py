@@ -175,6 +175,40 @@ def test_fbm_backward_vector_kernel_matches_scalar_kernel_bf16(sra, B, Cc, H, W)
     assert torch.isfinite(gz).all() and (gz - rz).abs().max().item() <= 1e-5 * max(1.0, rz.abs().max().item())
 
 
+@pytest.mark.parametrize('B,Cc,H,W', [(2, 64, 9, 11), (1, 96, 16, 16), (3, 192, 7, 5), (2, 32, 8, 8), (1, 160, 5, 9)])
+def test_input_gradient_vector_kernel_matches_scalar_kernel_bf16(sra, B, Cc, H, W):
+    """sr_fbm_gates_backward on bf16 tensors: the 16-bytes-per-lane input-gradient kernel (gate weights in LDS) against the
+    channel-per-lane kernel: equal up to the float32 summation order of the 27 gate terms, i.e. one bf16 ulp."""
+    from super_resolution_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(0)
+    m = sra.FDConv(Cc, 32, 3, padding=1).cuda()
+    for conv in m.FBM.freq_weight_conv_list:
+        torch.nn.init.normal_(conv.weight, std=0.2)
+    lp, keep = m.sr_layer_params(torch.bfloat16)
+    g = torch.Generator().manual_seed(31)
+    bf = lambda: torch.randn(B, H, W, Cc, generator=g).to(torch.bfloat16).cuda().contiguous()
+    x, dxd, a2, a4, a8 = bf(), bf(), bf(), bf(), bf()
+    dz = torch.cat([torch.randn(B, H, W, 3, generator=g), torch.zeros(B, H, W, 1)], 3).cuda().contiguous()
+    dpooled = (torch.randn(B, Cc, generator=g) * H * W).cuda().contiguous()
+    st = L.stream_ptr(torch.device('cuda:0'))
+    res = []
+    for scalar in (1, 0):
+        out = torch.full_like(x, float('nan'))
+        lib.sr_debug_wgrad_valu(scalar)
+        try:
+            L.check(lib.sr_fbm_gates_backward(1, B, H, W, L.view(x), dz.data_ptr(), C.byref(lp), L.view(dxd), L.view(a2), L.view(a4),
+                                              L.view(a8), dpooled.data_ptr(), Cc, L.view(out), None, None, st))
+            torch.cuda.synchronize()
+        finally:
+            lib.sr_debug_wgrad_valu(0)
+        res.append(out.float().cpu())
+    ref, got = res
+    assert torch.isfinite(got).all()
+    assert ((got - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-3).all(), (got - ref).abs().max().item()
+    assert (got != ref).float().mean().item() < 0.05  # a last-bit difference is rare
+
+
 # ------------------------------------------------------------------------------------------------------- layers
 @pytest.mark.parametrize('tag,cin,cout,B,h,w,pseed', [('c64_32', 64, 32, 4, 20, 24, 100), ('c192_64', 192, 64, 2, 16, 12, 104)])
 def test_fdconv_train_mode_gradients_vs_reference(sra, golden_r2, tag, cin, cout, B, h, w, pseed):
