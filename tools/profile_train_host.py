@@ -17,7 +17,7 @@ def main():
     torch.manual_seed(0)
     net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 23, 32)).cuda().train()
     net.compute_dtype = torch.bfloat16
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = train.FlatAdam(net.parameters(), lr=1e-4)
     wf = torch.rand(32, 1, 64, 64, device='cuda')
     sr = torch.rand(32, 1, 256, 256, device='cuda')
     for _ in range(2):
