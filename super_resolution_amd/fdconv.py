@@ -175,6 +175,12 @@ class FDConv(nn.Conv2d):
         self._sr_cache = {}
         return super()._apply(fn, *a, **k)
 
+    def __setattr__(self, name, value):
+        # a replaced parameter / submodule invalidates what is cached per module (parameter lists, packed weights)
+        if isinstance(value, (nn.Parameter, nn.Module)) and '_sr_cache' in self.__dict__:
+            self.__dict__['_sr_cache'] = {}
+        super().__setattr__(name, value)
+
     def group_map(self):
         """uint8 (3*cout, 3*cin//2+1) frequency-group id of every rfft2 bin, from `indices`."""
         idx = self.indices[0]
