@@ -16,11 +16,9 @@ def variant(name):
     """Returns a dynamic_weight with one piece swapped back to its earlier formulation."""
     if name == 'current':
         return T.dynamic_weight
-    src = T.dynamic_weight
 
     def fn(pooled, m, training):
         if name == 'conv1d':
-            orig_pad, orig_sig = F.pad, None
             # earlier formulation of KSM_Local: conv1d along the channel axis
             g, loc = m.KSM_Global, m.KSM_Local
             B, cin = pooled.shape
