@@ -414,6 +414,53 @@ __global__ __launch_bounds__(1024) void fbm_rows_fwd(View x, int ups, int pair, 
     }
 }
 
+// ---- kernel 1b: forward FFT along W of a nearest-2x upsampled tensor ---------------------------
+// The source row s (N = W / 2 pixels) appears as rows 2 hs, 2 hs + 1 of the upsampled image, every pixel twice:
+//     FFT_W(up s)[c] = (1 + w^c) FFT_N(s)[c mod N],   w = exp(-2 pi i / W),
+// so one N-point transform per SOURCE row serves two rows of T1: a quarter of the butterflies of fbm_rows_fwd on the
+// upsampled rows (conv_up1 / conv_up2 of a tiled image: 522 -> 1044, 1064 -> 2128).  tw = twiddles of length W.
+template <typename T>
+__global__ __launch_bounds__(1024) void fbm_rows_fwd_up(View x, int pair, int H, int W, int C, int PT, int P, Radix rx,
+                                                       const float2* __restrict__ tw, const int* __restrict__ cols, int n2,
+                                                       float2* __restrict__ t1, int ucut) {
+    const int lp = 31 - __clz(P);
+    const int N = W >> 1, Hs = H >> 1;
+    float2* bufA = (float2*)smem;
+    float2* bufB = bufA + N * P;
+    float2* twl = bufB + N * P;  // twiddles of the N-point transform: every second one of the W-point table
+    for (int i = threadIdx.x; i < N; i += blockDim.x) twl[i] = tw[2 * i];
+    const int b = blockIdx.x / Hs, hs = blockIdx.x % Hs;
+    const int p0 = blockIdx.y * P;
+    #pragma unroll 8
+    for (int it = threadIdx.x; it < N * P; it += blockDim.x) {
+        const int p = it & (P - 1), w = it >> lp;
+        const int c = 2 * (p0 + p);
+        const long pix = (long)hs * N + w;
+        float2 v = make_float2(0.f, 0.f);
+        if (pair) {
+            if (c < C) v = PairIO<T>::ld((const T*)x.p + voff(x, b, pix, c));
+        } else {
+            if (c < C) v.x = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c));
+            if (c + 1 < C) v.y = Elem<T>::ld((const T*)x.p + voff(x, b, pix, c + 1));
+        }
+        bufA[it] = v;
+    }
+    __syncthreads();
+    const float2* res = fft_run<false>(bufA, bufB, nullptr, false, N, rx, P, twl, nullptr, ucut);
+    #pragma unroll 4
+    for (int it = threadIdx.x; it < n2 * P; it += blockDim.x) {
+        const int p = it & (P - 1), idx = it >> lp;
+        if (p0 + p >= PT) continue;
+        const int c = cols[idx];
+        const float2 v = res[(c >= N ? c - N : c) * P + p];
+        const float2 w = tw[c];
+        const float2 o = make_float2(v.x + v.x * w.x - v.y * w.y, v.y + v.x * w.y + v.y * w.x);
+        float2* d = t1 + (((long)b * n2 + idx) * H + 2 * hs) * PT + p0 + p;
+        d[0] = o;
+        d[PT] = o;
+    }
+}
+
 // ---- kernel 2: FFT along H, row masks, inverse FFT along H ----------------------------------
 __global__ __launch_bounds__(1024) void fbm_cols(int H, int W, int PT, int P, Radix rx, Radix rxi, ColCuts cuts,
                                                 const float2* __restrict__ tw,
@@ -517,6 +564,9 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
 }
 
 int g_force_generic_fft = 0;  // test hook
+namespace fast {
+extern int g_no_ups_shortcut;  // debug hook (fbm_fast.hip): full-length transforms of upsampled sources
+}
 // bf16 planes of shapes that fbm_mfma.hip covers take its DFT-as-GEMM kernels; SR_AMD_LOWPASS=fft (or the debug hook
 // below) keeps them on the FFT kernels.
 int lowpass_default() {
@@ -584,7 +634,20 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
         SR_LDS_ATTR(lds_w, fbm_rows_inv<bf16_t>);
     }
     SR_LDS_ATTR(lds_h, fbm_cols);
-    if (dtype == SR_F32)
+    if (ups && pl->nfWu > 0 && !fast::g_no_ups_shortcut) {  // one half-length transform per source row
+        const int Pu = pl->Pwu;
+        const size_t lds_u = (2ul * (W / 2) * Pu + W / 2) * sizeof(float2);
+        const Radix ru = make_radix(pl->radWu, pl->nfWu);
+        const dim3 gu(B * (H / 2), cdiv(PT, Pu));
+        const int tu = threads_for(lds_u);
+        if (dtype == SR_F32) {
+            SR_LDS_ATTR(lds_u, fbm_rows_fwd_up<float>);
+            fbm_rows_fwd_up<float><<<gu, tu, lds_u, st>>>(x, pair_in, H, W, C, PT, Pu, ru, pl->tw_w, pl->cols, n2, t1, pl->ucutWu);
+        } else {
+            SR_LDS_ATTR(lds_u, fbm_rows_fwd_up<bf16_t>);
+            fbm_rows_fwd_up<bf16_t><<<gu, tu, lds_u, st>>>(x, pair_in, H, W, C, PT, Pu, ru, pl->tw_w, pl->cols, n2, t1, pl->ucutWu);
+        }
+    } else if (dtype == SR_F32)
         fbm_rows_fwd<float><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1, pl->ucutW);
     else
         fbm_rows_fwd<bf16_t><<<g1, tw_, lds_w, st>>>(x, ups, pair_in, H, W, C, PT, Pw, rw, pl->tw_w, pl->cols, n2, t1, pl->ucutW);
@@ -701,6 +764,19 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
         pl->ucutW = pl->ucutH = 0;
         for (int i = 0; i < 3; ++i) pl->tcutW[i] = 0;
         for (int i = 0; i < 9; ++i) pl->tcutH[i] = 0;
+        pl->nfWu = 0;
+        pl->ucutWu = 0;
+        if (W % 2 == 0 && H % 2 == 0 && W >= 4) {  // half-length row transform for nearest-2x upsampled sources
+            const int N = W / 2;
+            pl->nfWu = factorize(N, pl->radWu);
+            pl->Pwu = pairs_per_group(N, 2, env_int("SR_AMD_GENERIC_CAP_W", 0));
+            const int Ru = prime_radix(pl->radWu, pl->nfWu);
+            if (Ru) {
+                std::vector<char> used(N, 0);
+                for (int c : lists[0]) used[c >= N ? c - N : c] = 1;
+                pl->ucutWu = pair_cut(used, N, Ru);
+            }
+        }
         if (Rw) {
             for (int k = 0; k < 3; ++k) {
                 std::vector<char> used(W, 0);

@@ -23,6 +23,8 @@ struct sr_fbm_plan {
     int ucutW, ucutH;      // forward along W / H: output pairs u >= ucut fall on columns / rows no mask keeps
     int tcutW[3];          // inverse along W, band k: operand pairs t >= tcut hold no kept column
     int tcutH[9];          // inverse along H, [mask k][variant]: operand pairs t >= tcut have zero row-mask weights
+    // forward row transform of a nearest-2x upsampled source: one W/2-point transform per source row (fbm_rows_fwd_up)
+    int nfWu, radWu[24], Pwu, ucutWu;
     int row_zmask[9];      // [mask k][variant]: bit t set = rows [t*H/R0, (t+1)*H/R0) of that row mask are all zero (R0 = first radix of H)
     // ---- real-basis tables of the MFMA path (fbm_mfma.hip); mf_ok == 0 when the shape / masks are not covered ----
     int mf_ok;

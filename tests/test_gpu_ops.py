@@ -291,6 +291,31 @@ def test_fbm_lowpass_upsampled_and_bf16(L):
         assert (bands[k] - ref[k]).abs().max().item() < 4e-3
 
 
+@pytest.mark.parametrize('shape', [(1, 4, 33, 35), (2, 6, 29, 38), (1, 2, 87, 133), (1, 3, 20, 13), (1, 2, 64, 66)])
+def test_fbm_lowpass_any_size_upsampled_source_half_length_rows(L, shape):
+    """Any-size FFT with a nearest-2x upsampled source: one W/2-point transform per source row
+    (FFT_W(up s)[c] = (1 + w^c) FFT_{W/2}(s)[c mod W/2]) against the oracle on the upsampled tensor and against the
+    full-length transforms (debug hook); widths whose half has a prime factor beyond 7 take the pruned prime pass."""
+    lib = L.lib()
+    x = torch.from_numpy(gp.signed_input(shape, 17))
+    xu = F.interpolate(x, scale_factor=2, mode='nearest')
+    ref = fr.fbm_lowpass(xu.double()).float()
+    lib.sr_debug_force_generic_fft(1)
+    try:
+        bands, pooled = run_lowpass(L, x, torch.float32, ups=1)
+        lib.sr_debug_no_ups_shortcut(1)
+        try:
+            full, _ = run_lowpass(L, x, torch.float32, ups=1)
+        finally:
+            lib.sr_debug_no_ups_shortcut(0)
+    finally:
+        lib.sr_debug_force_generic_fft(0)
+    for k in range(3):
+        assert (bands[k] - ref[k]).abs().max().item() < 2e-5, (shape, k)
+        assert (bands[k] - full[k]).abs().max().item() < 2e-5, (shape, k)
+    assert (pooled - xu.mean(dim=(2, 3))).abs().max().item() < 1e-6
+
+
 def test_fbm_masks_host_matches_golden(L, golden):
     lib = L.lib()
     g = golden['fbm_masks']
