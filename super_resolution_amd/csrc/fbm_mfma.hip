@@ -35,6 +35,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -330,6 +331,7 @@ struct SynArgs {
     int tile0;          // first basis tile of this launch (waves take tiles tile0 .. tile0 + 15; M > 512 takes two launches)
     const h16* basis;   // fragment-major [pad32(M)][16 * nks_tab]
     int nks_tab;
+    int xtile;          // !SHARED: one more basis tile (index) served from LDS by waves 0..3, or -1 (see mf_synthesis)
     int bmask;          // bit k set = band k is produced
     int bfirst;         // first wanted band
     int bnext[3];       // wanted band after band k, or -1
@@ -358,6 +360,15 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             bq[ks][j] = ks < a.nks_tab ? *(const half8*)(a.basis + ((size_t)(tj[j] * a.nks_tab + ks) * 64 + lane) * 8) : zero_h8();
+    // !SHARED with 17 basis tiles (the 522 / 532-pixel rows of a tiled image: 544 columns, 16 tiles in the waves' registers):
+    // the 17th tile's fragments live in the window-image region of LDS, which the W-synthesis does not use, and waves 0..3
+    // multiply one item each by it after their own tiles -- a second launch for that tile streamed all of U again.
+    const bool xt = !SHARED && a.xtile >= 0;
+    if (xt) {
+        for (int ks = wave; ks < KS; ks += THREADS / 64)
+            *(half8*)(winimg + (ks * 64 + lane) * 16) =
+                ks < a.nks_tab ? *(const half8*)(a.basis + ((size_t)(a.xtile * a.nks_tab + ks) * 64 + lane) * 8) : zero_h8();
+    }
     // window weights (s, d) of this thread's window row (tid >> 4), one pair per band: kept in registers
     float2 wts[3];
 #pragma unroll
@@ -511,6 +522,30 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) store(gg, j, held[gg][j][0], held[gg][j][1]);
                     }
+                }
+                if (xt && wave < G) {  // wave-uniform: item `wave` of this group times the tile kept in LDS
+                    const int g = wave;
+                    const int ta0 = tr_addr<G>(lane, g, 0), ta1 = tr_addr<G>(lane, g, 1);
+                    f32x16 ax;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (ks && ks >= kend) break;
+                        const half8 d = tr_read(img + ks * 16 * ROWB, ta0, ta1);
+                        const half8 bx = *(const half8*)(winimg + (ks * 64 + lane) * 16);
+                        if (ks == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bx, z, 0, 0, 0);
+                        } else {
+                            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bx, ax, 0, 0, 0);
+                        }
+                    }
+                    uint4 lo, hi;
+                    tile_to_rows<!SHARED>(ax, 1.0f, lo, hi);
+                    const int ig = min(i0 + g, nit - 1), m = min(a.xtile * 32 + (lane & 31), a.Mv - 1);
+                    const View o = sel3(k, a.out[0], a.out[1], a.out[2]);
+                    uint4* dq = (uint4*)((bf16_t*)o.p + (long)b * o.bs + voff32(o, (unsigned)ig * a.Wout + m, cg * 32 + hk * 16));
+                    dq[0] = lo;
+                    dq[1] = hi;
                 }
             }
         }
@@ -906,6 +941,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     }
 
     SynArgs s3{};  // U_k = P (weights_k S)
+    s3.xtile = -1;
     for (int k = 0; k < 3; ++k) {
         s3.src[k] = S;
         s3.src_b[k] = (long)nh * jw * 32;
@@ -949,6 +985,7 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     }
 
     SynArgs s4{};  // L_k = U_k Qw_k^T
+    s4.xtile = -1;
     const View outs[3] = {l2, l4, l8};
     for (int k = 0; k < 3; ++k) {
         s4.src[k] = U[k];
@@ -987,7 +1024,10 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     } else {
         s4.basis = (const h16*)pl->mf_qw;
         s4.nks_tab = pl->mf_ld_qw / 16;
-        for (int t0 = 0; t0 < s4.M / 32; t0 += 16) {
+        const int ntile = s4.M / 32;
+        static const bool no_xtile = getenv("SR_AMD_NO_XTILE") != nullptr;  // A/B: the 17th tile in a second launch
+        s4.xtile = (ntile == 17 && !no_xtile) ? 16 : -1;  // 17 tiles: the last one from LDS in the same launch
+        for (int t0 = 0; t0 < (s4.xtile >= 0 ? 16 : ntile); t0 += 16) {
             s4.tile0 = t0;
             if (wide_s) {
                 SR_LDS_ATTR(lds_syn, mf_synthesis<false, 17>);
