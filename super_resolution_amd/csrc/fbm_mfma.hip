@@ -186,6 +186,8 @@ struct AnaArgs {
     int K, M, NB, CG, nitems;
     int tile0;        // first basis tile of this launch (waves take tiles tile0 .. tile0 + 7; M > 256 takes two launches)
     float scale;
+    int xtile1;       // KS = 34 only: 1 + index of one more basis tile with at most 16 valid functions, served from LDS by
+                      // waves 0 and 1 in the same launch (0 = none); see mf_analysis
     float* pooled;    // plane mean = DC coefficient * pool_scale (analysis along H only)
     int pooled_ld;
     float pool_scale;
@@ -214,6 +216,19 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
     for (int g = 0; g < G; ++g) {
         ta[g][0] = tr_addr<G>(lane, g, 0);
         ta[g][1] = tr_addr<G>(lane, g, 1);
+    }
+    // Ninth basis tile of the 522 / 532-pixel sides (262 / 266 functions: 8 tiles in the waves' registers + 6 / 10 functions):
+    // a second launch for it streamed the whole source again.  Its at most 16 distinct functions (the rest of the tile
+    // repeats the last one) take 512 bytes per k-step in the 24 KiB of LDS the two staged images leave free; after their own
+    // tile, waves 0 and 1 multiply one item each by it (lanes of functions 16..31 read function 15's fragment: zeros, as
+    // the table rows beyond its last function are).
+    const bool xt = KS == 34 && a.xtile1 > 0;
+    char* const xbasis = lds + 2 * IMG;
+    if (xt) {
+        for (int ks = wave; ks < KS; ks += THREADS / 64)
+            if ((lane & 31) < 16)
+                *(half8*)(xbasis + ((ks * 2 + (lane >> 5)) * 16 + (lane & 31)) * 16) =
+                    ks < nks ? *(const half8*)(a.basis + ((size_t)((a.xtile1 - 1) * nks + ks) * 64 + lane) * 8) : zero_h8();
     }
     const int gpb = (a.nitems + G - 1) / G, ngroups = a.NB * gpb;
     const int ch = tid & 7, r0 = tid >> 3, oct = ch & 3;  // loader: rows r0 + 64 i, 16-byte chunk ch (item ch >> 2)
@@ -292,6 +307,22 @@ __global__ __launch_bounds__(THREADS) void mf_analysis(AnaArgs a) {
                 uint4* d = (uint4*)(a.dst + (long)bcg * a.dst_b + (long)m * a.dst_m + (long)min(i0 + g, a.nitems - 1) * a.dst_i + hk * 16);
                 d[0] = lo[g];
                 d[1] = hi[g];
+            }
+            if (KS == 34 && xt && wave < G) {  // wave-uniform
+                const int g = wave;
+                const int t0a = tr_addr<G>(lane, g, 0), t1a = tr_addr<G>(lane, g, 1);
+                const char* xl = xbasis + ((lane >> 5) * 16 + min(lane & 31, 15)) * 16;
+                f32x16 ax;
+                zero_acc(ax);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_read(img + ks * 16 * ROWB, t0a, t1a), *(const half8*)(xl + ks * 512), ax, 0, 0, 0);
+                uint4 xlo, xhi;
+                tile_to_rows<false>(ax, a.scale, xlo, xhi);
+                const int mx = (a.xtile1 - 1) * 32 + (lane & 31);
+                uint4* d = (uint4*)(a.dst + (long)bcg * a.dst_b + (long)mx * a.dst_m + (long)min(i0 + g, a.nitems - 1) * a.dst_i + hk * 16);
+                d[0] = xlo;
+                d[1] = xhi;
             }
         }
         if (!more) break;
@@ -755,6 +786,8 @@ int fbm_mfma_plan_build(sr_fbm_plan* pl, const unsigned char* rows) {
     const int nh = 2 * (fmax[0] + 1);
     if (nh > 272) return SR_OK;
     // the kernels see both coefficient counts rounded up to whole basis tiles (the extra functions are zero)
+    pl->mf_jw_fill = jw;
+    pl->mf_nh_fill = nh;
     pl->mf_jw = pad_to(jw, 32);
     pl->mf_nh = pad_to(nh, 32);
     // y weights per band: ones up to the first frequency with s < 1 (main k-steps), then a window of 32 rows
@@ -899,8 +932,8 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     // crops of a training step, small inference inputs -- take instances of 4 or 8 steps instead of multiplying zeros
 #define SR_ANA(FV, KS_, ARGS, ITEMS)                                                                          \
     do {                                                                                                      \
-        SR_LDS_ATTR(2 * KS_ * 16 * 128, mf_analysis<FV, KS_>);                                                \
-        mf_analysis<FV, KS_><<<grid_for(ITEMS, 2), THREADS, 2 * KS_ * 16 * 128, st>>>(ARGS);                  \
+        SR_LDS_ATTR(2 * KS_ * 16 * 128 + (KS_ == 34 ? 34 * 512 : 0), mf_analysis<FV, KS_>);                   \
+        mf_analysis<FV, KS_><<<grid_for(ITEMS, 2), THREADS, 2 * KS_ * 16 * 128 + (KS_ == 34 ? 34 * 512 : 0), st>>>(ARGS); \
     } while (0)
 #define SR_ANA_BY_K(FV, K_, ARGS, ITEMS)                  \
     do {                                                  \
@@ -909,7 +942,12 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         else if ((K_) <= 512) SR_ANA(FV, 32, ARGS, ITEMS);\
         else SR_ANA(FV, 34, ARGS, ITEMS);                 \
     } while (0)
-    for (int t0 = 0; t0 < jw / 32; t0 += 8) {  // more than 8 basis tiles: the data is streamed once per 8 tiles
+    static const bool no_xtile_a = getenv("SR_AMD_NO_XTILE") != nullptr;  // A/B: the ninth tile in a second launch
+    // nine tiles whose last one has at most 16 distinct functions, on the 34-step instance: one launch
+    // (at most 15: the analysis tables hold zeros beyond their last function, and lanes 16..31 read function 15's fragment)
+    auto ninth_in_lds = [&](int K, int tiles, int valid) { return !no_xtile_a && K > 512 && tiles == 9 && valid - 256 <= 15; };
+    a1.xtile1 = ninth_in_lds(W, jw / 32, pl->mf_jw_fill) ? 9 : 0;
+    for (int t0 = 0; t0 < (a1.xtile1 ? 8 : jw / 32); t0 += 8) {  // more than 8 basis tiles: the data is streamed once per 8 tiles
         a1.tile0 = t0;
         SR_ANA_BY_K(true, W, a1, H);
         SR_LAUNCH_CHECK();
@@ -932,7 +970,8 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
     a2.nitems = pl->mf_nw[bfirst] + (pl->mf_nw[bfirst] & 1);  // coefficient columns of the widest wanted band
     a2.scale = 1.0f / 16.0f;
     a2.pool_scale = 4.0f / std::sqrt((float)H * (float)W);
-    for (int t0 = 0; t0 < nh / 32; t0 += 8) {
+    a2.xtile1 = ninth_in_lds(H, nh / 32, pl->mf_nh_fill) ? 9 : 0;
+    for (int t0 = 0; t0 < (a2.xtile1 ? 8 : nh / 32); t0 += 8) {
         a2.tile0 = t0;
         a2.pooled = t0 == 0 ? pooled : nullptr;
         a2.pooled_ld = pooled_ld;

@@ -32,6 +32,7 @@ struct sr_fbm_plan {
     int mf_nw[3];          // prefix of them kept by mask k
     int mf_nh;             // y-basis functions with non-zero weight in mask k=2 (same ordering)
     int mf_nhk[3];         // prefix with non-zero symmetric weight per mask
+    int mf_jw_fill, mf_nh_fill; // functions actually present in the analysis tables (rows beyond them are zero)
     int mf_ld_qw, mf_ld_ph; // padded k extents (multiples of 16) of the two synthesis tables
     void* mf_block;        // one device allocation: the tables below
     void* mf_qwt;          // fp16 [pad32(jw)][W]      q_j[w]        analysis along W
