@@ -272,6 +272,24 @@ def run_tiled(args, world, rank, dev, dist):
         sync()
         prof_all = net.profile_read()
         net.profile(False)
+        # content check of the gather (world > 1): rank 0 re-runs tiles that PEERS computed -- chosen among those whose
+        # place in the peer's run order differs from its place in the shard order -- and compares them with what was
+        # pasted into the gathered image
+        gather_err, gather_tiles = None, []
+        if world > 1 and rank == 0:
+            s4 = r.scale
+            for src in range(1, world):
+                shard = r.shard_of(wins, src, world)
+                ran = [i for part in r.batches_of(wins, shard, r.tile_batch) for i in part]
+                moved = [i for a, i in enumerate(shard) if ran[a] != i] or shard
+                gather_tiles += moved[:1] + moved[-1:]
+            gather_tiles = sorted(set(gather_tiles))[:4]
+            gather_err = 0.0
+            for i in gather_tiles:
+                (y0, y1, x0, x1) = wins[i][1]
+                again = r._run_tile(wins[i]).float()
+                got = out[:, :, y0 * s4:y1 * s4, x0 * s4:x1 * s4].float()
+                gather_err = max(gather_err, float((again - got).abs().max()))
         # whole enhance(), host image in -> host image out (PCIe, uint8 conversion and colour handling included)
         sync()
         t0 = time.perf_counter()
@@ -295,7 +313,7 @@ def run_tiled(args, world, rank, dev, dist):
         'config': {'workload': 'RealESRGANer(tile=%d, tile_pad=%d, pre_pad=0, half=True) x4 on one %dx%d synthetic RGB image, '
                                'RRDBNet-FDConv(3,3,64,23,32), bf16 (BASELINE.json configs[2])' % (args.tile, args.tile_pad, side, side),
                    'tiles': len(wins), 'tile_batch': args.tile_batch,
-                   'parallelism': '%d tiles area-sorted round-robin over %d rank(s), p2p gather of the cores to rank 0, no collective' % (len(wins), world),
+                   'parallelism': '%d tiles area-sorted round-robin over %d rank(s), one p2p message per peer (its cores stacked in shard order) to rank 0, no collective' % (len(wins), world),
                    'timed_region': 'tile_process() + post_process() with the padded image resident in HBM; max over ranks incl. the gather',
                    'enhance_host_to_host_s': t_enh, 'enhance_host_to_host_out_mpix_s': out_mpix / t_enh,
                    'pre_process_s': t_pre,
@@ -304,7 +322,10 @@ def run_tiled(args, world, rank, dev, dist):
                                                   'shrink with the number of ranks',
                                           'value': max(0.0, 1.0 - net_s / step_s), 'network_s': net_s,
                                           'enhance_minus_timed_s': t_enh - step_s},
-                   'output_ok': bool(out is None or torch.isfinite(out.float()).all()) and (full is None or full.shape == (4 * side, 4 * side, 3))},
+                   'gather_check': {'tiles_rerun_on_rank0': gather_tiles, 'max_abs_err': gather_err,
+                                    'note': 'tiles computed by peers, re-run on rank 0 and compared with the gathered image (null at N = 1)'},
+                   'output_ok': bool(out is None or torch.isfinite(out.float()).all()) and (full is None or full.shape == (4 * side, 4 * side, 3))
+                                and (gather_err is None or gather_err <= 2e-3)},
         'roofline': roofline_fields(prof, prof_all, args.steps, lr_px_rank, 3),
         'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},
         'kernel_launches_per_step': {k: v[1] for k, v in prof_all.items()},

@@ -696,13 +696,17 @@ int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float
         const bool two = (cout % 64 == 0);
         if (wlo % 8 != 0) return SR_ERR_ARG;
 #define SR_MFMA(MT, BANDS, SPLIT) launch_mfma<MT, BANDS, SPLIT>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
+        int rc;
         if (in.bands) {
-            if (wlo) return two ? SR_MFMA(2, true, 1) : SR_MFMA(1, true, 2);
-            return two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
+            if (wlo) rc = two ? SR_MFMA(2, true, 1) : SR_MFMA(1, true, 2);
+            else rc = two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
+        } else {
+            if (wlo) rc = two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);
+            else rc = two ? SR_MFMA(2, false, 0) : SR_MFMA(1, false, 0);
         }
-        if (wlo) return two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);
-        return two ? SR_MFMA(2, false, 0) : SR_MFMA(1, false, 0);
 #undef SR_MFMA
+        // a layer whose bias / slope tables push the LDS image past 160 KiB (very wide cout) is not an error: VALU kernel
+        if (rc != SR_NOT_ELIGIBLE) return rc;
     }
     return launch_generic<bf16_t>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
 }

@@ -34,12 +34,14 @@ class _ResizeL1(torch.autograd.Function):
         L.require_gpu(pred, 'resize_l1_loss')
         if pred.dtype != torch.float32 or target.dtype != torch.float32:
             raise TypeError('resize_l1_loss computes in float32')
+        # read BEFORE .contiguous(): forward runs in no-grad mode, so the contiguous copy of a channels_last prediction
+        # (any network with more than one output channel) has requires_grad = False
+        need_grad = ctx.needs_input_grad[0]
         pred, target = pred.contiguous(), target.contiguous()
         B, Cc, Hs, Ws = pred.shape
         Hd, Wd = target.shape[-2:]
         lib = L.lib()
         loss = torch.empty((), dtype=torch.float32, device=pred.device)
-        need_grad = pred.requires_grad
         grad = torch.empty_like(pred) if need_grad else None
         ws = torch.empty(lib.sr_resize_l1_workspace_bytes(), dtype=torch.uint8, device=pred.device)
         with torch.cuda.device(pred.device):

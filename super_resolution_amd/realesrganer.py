@@ -12,7 +12,8 @@ behind the same interface:
     8-bit path interpolates in 11-bit fixed point, this one in float32, so results may differ by 1 LSB);
   * when torch.distributed is initialised with world_size > 1 and `shard_tiles=True`, tile_process
     splits the tiles over the ranks (largest first, round-robin) and rank 0 gathers the pasted
-    centres with point-to-point transfers -- tiles are independent, so there is no collective.  Only
+    centres with ONE point-to-point message per peer (a flat stack of that peer's cores in shard_of()
+    order; no tags, no dependence on execution order) -- tiles are independent, so there is no collective.  Only
     rank 0 holds the assembled image: on the other ranks `self.output` is None after tile_process and
     `enhance` returns `(None, img_mode)`;
   * `tile_batch` (default 1 = the reference's one tile at a time, same peak memory) runs that many
@@ -126,6 +127,18 @@ class RealESRGANer():
         order = sorted(range(len(wins)), key=lambda i: (-(wins[i][0][1] - wins[i][0][0]) * (wins[i][0][3] - wins[i][0][2]), i))
         return [order[i] for i in range(rank, len(order), world)]
 
+    @classmethod
+    def shard_layout(cls, wins, rank, world, batch, channel, scale):
+        """Where rank `rank` packs its output cores for the gather: [(tile index, element offset, core shape)] in
+        shard_of() order, and the total element count.  Sender and receiver both derive it from the geometry."""
+        out, off = [], 0
+        for i in cls.shard_of(wins, rank, world):
+            (y0, y1, x0, x1) = wins[i][1]
+            shape = (batch, channel, (y1 - y0) * scale, (x1 - x0) * scale)
+            out.append((i, off, shape))
+            off += math.prod(shape)
+        return out, off
+
     def _run_tile(self, win):
         (py0, py1, px0, px1), (y0, y1, x0, x1), (oy, ox) = win
         s = self.scale
@@ -133,27 +146,31 @@ class RealESRGANer():
             out = self.model(self.img[:, :, py0:py1, px0:px1])
         return out[:, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s]
 
-    def _run_tiles(self, wins, idxs, sink=None):
-        """Output cores of the tiles `idxs`; tiles with equal window size share batches of `tile_batch`.  With `sink`
-        every core is handed to sink(index, tensor) as soon as it exists (nothing is kept), else a dict is returned."""
+    @staticmethod
+    def batches_of(wins, idxs, tile_batch):
+        """The forwards that cover the tiles `idxs`, in execution order: tiles of equal window size share batches of
+        `tile_batch` (so the execution order is NOT the order of `idxs` -- the gather must not depend on it)."""
         groups = {}
         for i in idxs:
             (py0, py1, px0, px1) = wins[i][0]
             groups.setdefault((py1 - py0, px1 - px0), []).append(i)
+        return [members[k:k + tile_batch] for members in groups.values() for k in range(0, len(members), tile_batch)]
+
+    def _run_tiles(self, wins, idxs, sink=None):
+        """Output cores of the tiles `idxs`, batched as batches_of() says.  With `sink` every core is handed to
+        sink(index, tensor) as soon as it exists (nothing is kept), else a dict is returned."""
         s, nb, done = self.scale, self.img.shape[0], {}
         put = sink if sink is not None else done.__setitem__
-        for members in groups.values():
-            for k in range(0, len(members), self.tile_batch):
-                part = members[k:k + self.tile_batch]
-                if len(part) == 1:
-                    put(part[0], self._run_tile(wins[part[0]]))
-                    continue
-                crops = torch.cat([self.img[:, :, wins[i][0][0]:wins[i][0][1], wins[i][0][2]:wins[i][0][3]] for i in part], 0)
-                with torch.no_grad():
-                    out = self.model(crops)
-                for j, i in enumerate(part):
-                    (y0, y1, x0, x1), (oy, ox) = wins[i][1], wins[i][2]
-                    put(i, out[j * nb:(j + 1) * nb, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s])
+        for part in self.batches_of(wins, idxs, self.tile_batch):
+            if len(part) == 1:
+                put(part[0], self._run_tile(wins[part[0]]))
+                continue
+            crops = torch.cat([self.img[:, :, wins[i][0][0]:wins[i][0][1], wins[i][0][2]:wins[i][0][3]] for i in part], 0)
+            with torch.no_grad():
+                out = self.model(crops)
+            for j, i in enumerate(part):
+                (y0, y1, x0, x1), (oy, ox) = wins[i][1], wins[i][2]
+                put(i, out[j * nb:(j + 1) * nb, :, oy * s:(oy + y1 - y0) * s, ox * s:(ox + x1 - x0) * s])
         return done
 
     def tile_process(self):
@@ -174,32 +191,37 @@ class RealESRGANer():
         if world == 1:
             self._run_tiles(wins, range(len(wins)), sink=paste)
             return
+        # Gather: every peer packs the cores of its tiles into ONE flat buffer laid out in shard_of() order (the
+        # offsets depend on the tile geometry only, never on the order the tiles were run in) and sends it as one
+        # message once its tiles are done; rank 0 receives one message per peer AFTER its own tiles.  Message matching
+        # therefore needs neither tags (RCCL ignores them) nor an agreed execution order, and no receive kernel sits in
+        # front of rank 0's compute.
         mine = self.shard_of(wins, rank, world)
         if rank == 0:
-            # post every receive first, so the peers' sends complete while this rank is still computing its own tiles
-            bufs, reqs = [], []
-            for src in range(1, world):
-                for i in self.shard_of(wins, src, world):
-                    (y0, y1, x0, x1) = wins[i][1]
-                    buf = self.img.new_empty((batch, channel, (y1 - y0) * s, (x1 - x0) * s))
-                    reqs.append(dist.irecv(buf, src=src, tag=i))
-                    bufs.append((i, buf))
             self._run_tiles(wins, mine, sink=paste)
-            for r in reqs:
+            stacks = []
+            for src in range(1, world):
+                layout, total = self.shard_layout(wins, src, world, batch, channel, s)
+                stacks.append((layout, self.img.new_empty(total)))
+            ops = [dist.P2POp(dist.irecv, buf, src) for src, (_, buf) in enumerate(stacks, start=1) if buf.numel()]
+            for r in (dist.batch_isend_irecv(ops) if ops else []):
                 r.wait()
-            for i, buf in bufs:
-                paste(i, buf)
+            for layout, buf in stacks:
+                for i, off, shape in layout:
+                    paste(i, buf[off:off + math.prod(shape)].view(shape))
         else:
             self.output = None  # only rank 0 assembles the image
-            reqs, keep = [], []
+            layout, total = self.shard_layout(wins, rank, world, batch, channel, s)
+            place = {i: (off, shape) for i, off, shape in layout}
+            stack = self.img.new_empty(total)
 
-            def send(i, t):
-                t = t.contiguous()
-                keep.append(t)
-                reqs.append(dist.isend(t, dst=0, tag=i))
-            self._run_tiles(wins, mine, sink=send)
-            for r in reqs:
-                r.wait()
+            def pack(i, t):
+                off, shape = place[i]
+                stack[off:off + math.prod(shape)].view(shape).copy_(t)
+            self._run_tiles(wins, mine, sink=pack)
+            if total:
+                for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, stack, 0)]):
+                    r.wait()
 
     def post_process(self):
         """Crop the mod-pad and the pre-pad off the upscaled image (utils.py:182-191); None on ranks without the image."""

@@ -67,9 +67,12 @@ class SRVGGNetCompact(nn.Module):
             L.require_gpu(w, 'SRVGGNetCompact')
             cout, cin = m.out_channels, m.in_channels
             last = i == len(convs) - 1
-            # bf16: the MFMA kernel takes 32-channel output tiles or thin (<= 16) outputs; pad the last conv's 48 to 64
+            # bf16: the MFMA kernel takes 32-channel output tiles or thin (<= 16) outputs; pad the LAST conv's 48 to 64 (its
+            # destination is sized for the padded count and sr_pixel_shuffle_add reads the first num_out_ch * r * r).
+            # Hidden layers are never padded -- their slopes, ping-pong buffers and the next layer's cin are num_feat wide;
+            # a num_feat that is not a multiple of 32 takes the generic conv kernel.
             cpad = cout
-            if dtype == torch.bfloat16 and cout > 16 and cout % 32:
+            if last and dtype == torch.bfloat16 and cout > 16 and cout % 32 and cin % 32 == 0:
                 cpad = (cout + 31) // 32 * 32
             if cpad != cout:
                 w = torch.cat([w, w.new_zeros(cpad - cout, cin, 3, 3)], 0)

@@ -458,7 +458,7 @@ def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20, average=T
     return len(buckets)
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """Adam (torch.optim.Adam's update rule: `weight_decay` L2, no amsgrad) over ONE flat float32 buffer.
 
     RRDBNet-FDConv has ~6000 parameter tensors of a few KB each; per step torch.optim.Adam spends 0.18 s of host time
@@ -468,36 +468,58 @@ class FlatAdam:
     norm, and updates parameters and moments with five tensor ops.  Parameters that received no gradient in a step count
     as zero gradients (torch.optim.Adam skips them; every parameter of the networks here gets one).
 
-    Usage: `opt = FlatAdam(net.parameters(), lr=1e-4)`; `opt.zero_grad()`; ...; `opt.step()` -- or pass it to `train_step`.
-    Call it after the module has been moved to its device."""
+    It is a `torch.optim.Optimizer`: the learning-rate schedulers of the owner scripts accept it
+    (train/train_realESRGAN_fdconv.py:121 ReduceLROnPlateau; the rate is read from `param_groups[0]` at every step) and
+    `state_dict()` / `load_state_dict()` use torch.optim.Adam's own layout (per-parameter `step`, `exp_avg`, `exp_avg_sq`),
+    so a checkpoint written as in train/train_realESRGAN_fdconv_OST_1.py:401 resumes under either optimizer.
+    In a process group of more than one rank the constructor broadcasts rank 0's parameters, so that replicas start equal
+    whatever their seeds (`broadcast=False` to skip).
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+    Usage: `opt = FlatAdam(net.parameters(), lr=1e-4)`; `opt.zero_grad()`; ...; `opt.step()` -- or pass it to `train_step`.
+    Construct it AFTER the module has been moved / cast to its final device and dtype: `.to()` / `.float()` re-allocate
+    the parameters and break the aliasing (step() checks and raises)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, broadcast=True, group=None):
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            raise ValueError('FlatAdam: one parameter group (pass the parameters, not a list of groups)')
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError('FlatAdam: no parameters')
-        dev = self.params[0].device
-        for p in self.params:
+        dev = params[0].device
+        for p in params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise TypeError('FlatAdam: float32 parameters on one device')
-        self.param_groups = [{'params': self.params, 'lr': lr, 'betas': betas, 'eps': eps, 'weight_decay': weight_decay}]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.params = self.param_groups[0]['params']
         self.sizes = [p.numel() for p in self.params]
         n = sum(self.sizes)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         off = 0
+        self._offsets = []
         with torch.no_grad():
             for p, k in zip(self.params, self.sizes):
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)   # the module's parameters now alias the flat buffer
+                self._offsets.append(off)
                 off += k
+        self._ptrs = [p.data_ptr() for p in self.params]
         self.grad = None  # the flat gradient of the last step
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
         self._zeros = None
+        import torch.distributed as dist
+        if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            torch.autograd.graph.increment_version(self.params)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
-            p.grad = None
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.detach_().zero_()
 
     def gather_gradients(self):
         """p.grad of every parameter -> one flat tensor (a single C++ flatten: a Python loop of 6000 reshapes cost 0.1 s per
@@ -514,8 +536,15 @@ class FlatAdam:
         return self.grad
 
     @torch.no_grad()
-    def step(self, group=None, average=True, clip_grad_norm=None):
+    def step(self, closure=None, group=None, average=True, clip_grad_norm=None):
         import torch.distributed as dist
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if [p.data_ptr() for p in self.params] != self._ptrs:
+            raise RuntimeError('FlatAdam: a parameter no longer aliases the flat buffer (the module was moved or cast with '
+                               '.to() / .float() / .cuda() after the optimizer was built) -- rebuild the optimizer')
         g = self.gather_gradients()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
@@ -536,6 +565,42 @@ class FlatAdam:
         # the update went through the flat buffer: a parameter re-pointed with `.data =` keeps its own version counter, and
         # everything keyed on it (FDConv's cached spectral bases, autograd's saved-tensor checks) must see the change
         torch.autograd.graph.increment_version(self.params)
+        return loss
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}."""
+        state = {}
+        if self.steps:
+            for i, (p, off, k) in enumerate(zip(self.params, self._offsets, self.sizes)):
+                state[i] = {'step': torch.tensor(float(self.steps)),
+                            'exp_avg': self.exp_avg[off:off + k].view(p.shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+        hp = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        hp['params'] = list(range(len(self.params)))
+        return {'state': state, 'param_groups': [hp]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.params):
+            raise ValueError('FlatAdam.load_state_dict: expected one group of %d parameters' % len(self.params))
+        for k, v in groups[0].items():
+            if k != 'params' and k in self.param_groups[0]:
+                self.param_groups[0][k] = v
+        state = sd['state']
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = 0
+        for key, st in state.items():
+            i = int(key)
+            off, k = self._offsets[i], self.sizes[i]
+            if tuple(st['exp_avg'].shape) != tuple(self.params[i].shape):
+                raise ValueError('FlatAdam.load_state_dict: parameter %d has shape %s, state %s'
+                                 % (i, tuple(self.params[i].shape), tuple(st['exp_avg'].shape)))
+            self.exp_avg[off:off + k].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+            steps = max(steps, int(float(st['step'])))
+        self.steps = steps
 
 
 def train_step(net, optimizer, wf, sr, weighted=False, sigmoid=False, clip_grad_norm=None, group=None):

@@ -310,3 +310,60 @@ def test_flat_adam_matches_torch_adam():
         assert all(p._version > v for p, v in zip(b.parameters(), v0))
         # the parameters are views of the flat buffer
         assert all(p.data_ptr() >= ob.flat.data_ptr() for p in b.parameters())
+
+
+def test_flat_adam_is_an_optimizer_checkpoints_and_guards_its_aliasing():
+    """Round-2 advisor finding: the owner scripts attach ReduceLROnPlateau to the optimizer
+    (train/train_realESRGAN_fdconv.py:121) and checkpoint optimizer.state_dict()
+    (train/train_realESRGAN_fdconv_OST_1.py:401).  FlatAdam must be a torch.optim.Optimizer, follow a scheduler's rate,
+    save / resume its moments in torch.optim.Adam's own layout, and notice a module cast after construction."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from super_resolution_amd.train import FlatAdam
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Linear(6, 4), nn.Tanh(), nn.Linear(4, 2))
+    twin = copy.deepcopy(net)
+    opt, ref = FlatAdam(net.parameters(), lr=1e-2), torch.optim.Adam(twin.parameters(), lr=1e-2)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.5, patience=0)
+    sch_ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref, mode='min', factor=0.5, patience=0)
+    xs = [torch.randn(3, 6) for _ in range(6)]
+
+    def run(model, o, x):
+        o.zero_grad()
+        model(x).pow(2).sum().backward()
+        o.step()
+    for i in range(3):
+        run(net, opt, xs[i])
+        run(twin, ref, xs[i])
+        sch.step(1.0)        # a plateau: the rate halves from the second call on
+        sch_ref.step(1.0)
+    assert opt.param_groups[0]['lr'] == ref.param_groups[0]['lr'] < 1e-2
+    for pa, pb in zip(net.parameters(), twin.parameters()):
+        assert (pa - pb).abs().max().item() < 2e-6
+    # checkpoint in Adam's layout; resume into a fresh FlatAdam AND into torch.optim.Adam, continue, compare
+    ck = opt.state_dict()
+    assert set(ck) == {'state', 'param_groups'} and set(ck['state'][0]) >= {'step', 'exp_avg', 'exp_avg_sq'}
+    net2, net3 = copy.deepcopy(net), copy.deepcopy(net)
+    opt2 = FlatAdam(net2.parameters(), lr=123.0)
+    opt2.load_state_dict(ck)
+    opt3 = torch.optim.Adam(net3.parameters(), lr=123.0)
+    opt3.load_state_dict(ck)
+    assert opt2.steps == 3 and opt2.param_groups[0]['lr'] == opt.param_groups[0]['lr']
+    for i in range(3, 6):
+        run(net, opt, xs[i])
+        run(net2, opt2, xs[i])
+        run(net3, opt3, xs[i])
+    for pa, pb, pc in zip(net.parameters(), net2.parameters(), net3.parameters()):
+        assert torch.equal(pa, pb)
+        assert (pa - pc).abs().max().item() < 2e-6
+    # zero_grad(set_to_none=False) keeps zeroed gradient tensors
+    opt.zero_grad(set_to_none=False)
+    assert all(p.grad is not None and not p.grad.any() for p in net.parameters())
+    # a cast after construction re-allocates the parameters: step() must refuse instead of updating a dead buffer
+    net.double()
+    net.float()
+    net(xs[0]).sum().backward()
+    with pytest.raises(RuntimeError, match='no longer aliases'):
+        opt.step()

@@ -93,3 +93,41 @@ def test_resize_l1_loss_and_gradient_match_torch(weighted, sigmoid):
     (loss * 3.0).backward()
     assert abs(loss.item() - ref.item()) < 1e-6
     assert (pg.grad.cpu() - p.grad).abs().max().item() < 1e-8 + 1e-5 * p.grad.abs().max().item()
+
+
+def test_resize_l1_loss_gradient_reaches_a_channels_last_rgb_prediction():
+    """Round-2 advisor finding: `requires_grad` was read from the .contiguous() copy of the prediction, which -- forward
+    running in no-grad mode -- never requires grad: a 3-channel prediction in channels_last memory (what the training
+    path hands over) received no gradient at all and FlatAdam substituted zeros."""
+    from super_resolution_amd import head
+    g = torch.Generator().manual_seed(8)
+    base = torch.randn(2, 3, 24, 20, generator=g)
+    target = torch.rand(2, 3, 60, 50, generator=g)
+    p = base.clone().requires_grad_(True)
+    ref = torch.mean(torch.abs(F.interpolate(p, size=(60, 50), mode='bilinear', align_corners=False) - target))
+    ref.backward()
+    leaf = base.cuda().requires_grad_(True)
+    pred = (leaf * 1.0).contiguous(memory_format=torch.channels_last)   # non-contiguous as NCHW, part of a graph
+    assert not pred.is_contiguous()
+    loss = head.resize_l1_loss(pred, target.cuda())
+    loss.backward()
+    assert leaf.grad is not None
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert (leaf.grad.cpu() - p.grad).abs().max().item() < 1e-8 + 1e-5 * p.grad.abs().max().item()
+
+
+def test_srvgg_bf16_with_a_feature_width_that_is_not_a_multiple_of_32():
+    """Round-2 advisor finding: hidden layers were padded to a 32-channel tile while their slopes, buffers and the next
+    layer's input width were not.  num_feat = 48 must run (generic conv kernel) and agree with the float32 path."""
+    from super_resolution_amd import SRVGGNetCompact
+    args = (3, 3, 48, 2, 4)
+    net = SRVGGNetCompact(*args, act_type='prelu')
+    net.load_state_dict(t(gp.srvgg_state(*args, seed=610, act_type='prelu')), strict=True)
+    net = net.eval().cuda()
+    x = torch.from_numpy(gp.image_input((1, 3, 20, 28), seed=611)).cuda()
+    with torch.no_grad():
+        y = net(x)
+        yb = net(x.to(torch.bfloat16)).float()
+        ref = srvgg_forward(t(gp.srvgg_state(*args, seed=610, act_type='prelu')), x.cpu())
+    assert (y.cpu() - ref).abs().max().item() < 1e-4
+    assert (yb.cpu() - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
