@@ -112,20 +112,24 @@ def build_model(device, ch=1, seed=1234):
 
 
 def cpu_baseline(sd, sample_hw, ch=1):
-    """Oracle forward on the host cores on a bounded sample; returns the dict for the JSON line."""
+    """Oracle forward on the host cores on a bounded sample (SURVEY 8d: one warm-up, then the median of three runs);
+    returns the dict for the JSON line."""
     from oracle.rrdbnet_ref import rrdbnet_forward
     threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or torch.get_num_threads()
     torch.set_num_threads(threads)
     x = synthetic_batch(1, sample_hw, sample_hw, 'cpu')
     if ch > 1:
         x = x.expand(1, ch, sample_hw, sample_hw).contiguous()
-    t0 = time.perf_counter()
+    times = []
     with torch.no_grad():
-        y = rrdbnet_forward(sd, x)
-    dt = time.perf_counter() - t0
+        for _ in range(4):
+            t0 = time.perf_counter()
+            y = rrdbnet_forward(sd, x)
+            times.append(time.perf_counter() - t0)
+    dt = float(np.median(times[1:]))
     return {'value': y.shape[-1] * y.shape[-2] / 1e6 / dt, 'unit': 'output Mpix/s', 'cores': threads, 'kind': 'port',
-            'sample': 'one forward of the same 23-block RRDBNet-FDConv on 1x%dx%dx%d (fp32 torch oracle, %.1f s), '
-                      'no extrapolation' % (ch, sample_hw, sample_hw, dt)}
+            'sample': 'forward of the same 23-block RRDBNet-FDConv on 1x%dx%dx%d (fp32 torch oracle): 1 warm-up (%.1f s) + median '
+                      'of 3 runs (%.1f s), no extrapolation' % (ch, sample_hw, sample_hw, times[0], dt)}
 
 
 def roofline_fields(prof, prof_all, steps, lr_px_step, ch):
@@ -475,8 +479,9 @@ def main():
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--tile-pad', type=int, default=10)
     ap.add_argument('--tile-batch', type=int, default=18, help='tiled: tiles of equal window size per forward (8 -> 18: 45.7 -> 49.2 out-Mpix/s at N = 1)')
-    ap.add_argument('--cpu-sample', type=int, default=208, help='side of the CPU-baseline sample image (0: skip)')
+    ap.add_argument('--cpu-sample', type=int, default=128, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
+    ap.add_argument('--no-secondary', action='store_true', help='batch: skip the one-step runs of the tiled / train / srvgg configs')
     ap.add_argument('--no-split-weights', action='store_true', help='A/B: plain bf16 dynamic weights instead of hi + lo pairs')
     args = ap.parse_args()
 
@@ -501,7 +506,29 @@ def main():
     if args.no_split_weights:
         from super_resolution_amd import _lib
         _lib.lib().sr_debug_split_weights(0)
-    res = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch, 'train': run_train}[args.config](args, world, rank, dev, dist)
+    runners = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch, 'train': run_train}
+    res = runners[args.config](args, world, rank, dev, dist)
+    if args.config == 'batch' and world == 1 and not args.no_secondary:
+        # the other BASELINE configs, one short timed step each, so that the driver's one command sees them too
+        # (each also runs on its own and at N > 1 with --config)
+        import copy
+        import gc
+        res['secondary'] = {}
+        for name in ('tiled', 'train', 'srvgg'):
+            gc.collect()
+            torch.cuda.empty_cache()
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.no_cpu_baseline = (3 if name == 'srvgg' else 1), 1, True
+            t0 = time.perf_counter()
+            try:
+                r2 = runners[name](a2, world, rank, dev, dist)
+                res['secondary'][name] = {'value': r2['value'], 'unit': r2['unit'], 'ms_per_step': r2['ms_per_step'], 'steps': a2.steps,
+                                          'dtype': r2['dtype'], 'scaling': r2['scaling'], 'workload': r2['config']['workload'],
+                                          'roofline_bound': r2['roofline']['bound'], 'roofline_frac': r2['roofline']['frac'],
+                                          'detail': {k: v for k, v in r2['config'].items() if k not in ('workload',)},
+                                          'wall_s': time.perf_counter() - t0}
+            except Exception as e:  # a secondary config must never take the headline line down with it
+                res['secondary'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -226,6 +226,20 @@ size_t sr_resize_l1_workspace_bytes(void);
 int sr_resize_l1_loss(const float* pred, const float* target, long planes, int Hs, int Ws, int Hd, int Wd, int weighted,
                       int pre_sigmoid, float* loss, float* grad_pred, void* workspace, size_t workspace_bytes, void* stream);
 
+/* RealESRGANer.enhance's image ends (Real-ESRGAN-master/realesrgan/utils.py:197-216 and :225-254), so that the
+ * host <-> device transfers carry the INTEGER image (a 16384^2 RGB result is 0.8 GB as uint8, 3.2 GB as float32):
+ * sr_image_to_planes: src (H,W,channels) HWC device image, src_kind 0 = uint8, 1 = uint16, 2 = float32 ->
+ *   dst (3,H,W) float planes, plane j = (float)src[..., cj] / full  (img.astype(np.float32) / 255 | 65535 at :197-203 and the
+ *   channel shuffles of cv2.cvtColor at :204-216: BGR -> RGB = (2,1,0), gray -> RGB = (0,0,0), alpha = (3,3,3)).
+ * sr_image_from_planes: src = R, G, B planes of the network output (element strides plane_stride / row_stride: the
+ *   post_process crop is a strided view) -> dst (H,W,dst_channels) HWC uint8 (sixteen = 0) / uint16 (sixteen = 1) image,
+ *   channels dst_c0.. : clamp_(0, 1) (:225), RGB -> BGR (:226) or, gray != 0, COLOR_BGR2GRAY (:228, 0.114 B + 0.587 G + 0.299 R),
+ *   x 255 | 65535, round half to even, cast (:251-254). */
+int sr_image_to_planes(const void* src, int src_kind, int H, int W, int channels, int c0, int c1, int c2, float full, float* dst,
+                       void* stream);
+int sr_image_from_planes(const void* src, int src_dtype, int H, int W, long plane_stride, long row_stride, int gray, int sixteen,
+                         void* dst, int dst_channels, int dst_c0, void* stream);
+
 /* ---- training: backward of one conv / FDConv layer ------------------------------------------
  * The reference obtains these from torch autograd through FDConv.py:640-722 (loss.backward() at
  * train/train_realESRGAN_fdconv_1.py:117).  Layer forward:  y = bias + conv3x3(a, W_b),  a = FBM(x) (see sr_conv3x3).

@@ -88,6 +88,10 @@ _SIGS = {
     'sr_resize_l1_workspace_bytes': (C.c_size_t, []),
     'sr_resize_l1_loss': (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_image_to_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                     C.c_void_p]),
+    'sr_image_from_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p]),
     'sr_rrdbnet_create': (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
     'sr_rrdbnet_destroy': (None, [C.c_void_p]),
     'sr_rrdbnet_num_layers': (C.c_int, [C.c_void_p]),

@@ -122,6 +122,45 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, int n, fl
     }
 }
 
+// ---- RealESRGANer.enhance's image ends ----------------------------------------------------------------------------
+// in:  HWC integer / float image -> three float planes  plane[j] = (float)img[h][w][chmap[j]] / full   (utils.py:197-216:
+//      astype(float32), / 255 or / 65535, BGR -> RGB / gray -> RGB / alpha -> 3 equal planes)
+template <typename TS>
+__global__ void image_to_planes_kernel(const TS* __restrict__ src, int H, int W, int channels, int c0, int c1, int c2, float full,
+                                       float* __restrict__ dst) {
+    const long n = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const TS* px = src + i * channels;
+        dst[i] = __fdiv_rn((float)px[c0], full);
+        dst[n + i] = __fdiv_rn((float)px[c1], full);
+        dst[2 * n + i] = __fdiv_rn((float)px[c2], full);
+    }
+}
+
+// out: three float / bf16 planes (R, G, B) -> HWC integer image (utils.py:225-228, 251-254): clamp to [0, 1], RGB -> BGR or
+//      BGR2GRAY (0.114 B + 0.587 G + 0.299 R, float32, left to right, no contraction), x full, round half to even, saturate.
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+template <typename TS, typename TD>
+__global__ void image_from_planes_kernel(const TS* __restrict__ src, int H, int W, long plane_stride, long row_stride, int gray,
+                                         float full, TD* __restrict__ dst, int dst_channels, int dst_c0) {
+    const long n = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(i / W), w = (int)(i - (long)h * W);
+        const TS* p = src + (long)h * row_stride + w;
+        const float r = clamp01(Elem<TS>::ld(p)), g = clamp01(Elem<TS>::ld(p + plane_stride)), b = clamp01(Elem<TS>::ld(p + 2 * plane_stride));
+        TD* o = dst + i * dst_channels + dst_c0;
+        if (gray) {
+            const float y = __fadd_rn(__fadd_rn(__fmul_rn(0.114f, b), __fmul_rn(0.587f, g)), __fmul_rn(0.299f, r));
+            o[0] = (TD)rintf(__fmul_rn(y, full));
+        } else {
+            o[0] = (TD)rintf(__fmul_rn(b, full));
+            o[1] = (TD)rintf(__fmul_rn(g, full));
+            o[2] = (TD)rintf(__fmul_rn(r, full));
+        }
+    }
+}
+
 static int head_grid(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -179,6 +218,38 @@ extern "C" int sr_resize_l1_loss(const float* pred, const float* target, long pl
                                         (float*)workspace, grad_pred);
     SR_LAUNCH_CHECK();
     sum_partials_kernel<<<1, 64, 0, st>>>((const float*)workspace, g, 1.0f / (float)n, loss);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_image_to_planes(const void* src, int src_kind, int H, int W, int channels, int c0, int c1, int c2, float full,
+                                  float* dst, void* stream) {
+    SR_REQUIRE(src && dst && H > 0 && W > 0 && channels >= 1 && channels <= 4 && full > 0.f);
+    SR_REQUIRE(c0 >= 0 && c0 < channels && c1 >= 0 && c1 < channels && c2 >= 0 && c2 < channels);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid((long)H * W);
+    if (src_kind == 0) image_to_planes_kernel<uint8_t><<<g, 256, 0, st>>>((const uint8_t*)src, H, W, channels, c0, c1, c2, full, dst);
+    else if (src_kind == 1) image_to_planes_kernel<uint16_t><<<g, 256, 0, st>>>((const uint16_t*)src, H, W, channels, c0, c1, c2, full, dst);
+    else if (src_kind == 2) image_to_planes_kernel<float><<<g, 256, 0, st>>>((const float*)src, H, W, channels, c0, c1, c2, full, dst);
+    else return SR_ERR_ARG;
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_image_from_planes(const void* src, int src_dtype, int H, int W, long plane_stride, long row_stride, int gray,
+                                    int sixteen, void* dst, int dst_channels, int dst_c0, void* stream) {
+    SR_REQUIRE(src && dst && dtype_ok(src_dtype) && H > 0 && W > 0 && row_stride >= W && plane_stride >= (long)(H - 1) * row_stride + W);
+    SR_REQUIRE(dst_channels >= 1 && dst_channels <= 4 && dst_c0 >= 0 && dst_c0 + (gray ? 1 : 3) <= dst_channels);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid((long)H * W);
+    const float full = sixteen ? 65535.f : 255.f;
+#define SR_IM(TS, TD) \
+    image_from_planes_kernel<TS, TD><<<g, 256, 0, st>>>((const TS*)src, H, W, plane_stride, row_stride, gray, full, (TD*)dst, dst_channels, dst_c0)
+    if (src_dtype == SR_F32 && sixteen) SR_IM(float, uint16_t);
+    else if (src_dtype == SR_F32) SR_IM(float, uint8_t);
+    else if (sixteen) SR_IM(bf16_t, uint16_t);
+    else SR_IM(bf16_t, uint8_t);
+#undef SR_IM
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

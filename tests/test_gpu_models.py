@@ -227,6 +227,33 @@ def test_enhance_modes_vs_oracle(sra):
     assert np.array_equal(out2, lanczos4_resize(out4, 22, 17))
 
 
+@pytest.mark.parametrize('half', [False, True])
+def test_enhance_device_image_path_is_bit_identical_to_the_numpy_steps(sra, half):
+    """enhance() on a GPU converts the caller's integer image to float planes and the result back to the integer image with
+    two kernels (sr_image_to_planes / sr_image_from_planes) so that only integers cross PCIe; the numpy steps of
+    utils.py:197-254 (`_enhance_host`) are the yardstick: every mode, bit for bit."""
+    sd = t(gp.rrdbnet_state(3, 3, 8, 1, 4, seed=9, fdconv=False))
+    net = build_net(sra, (3, 3, 4, 8, 1, 4), sd, False)
+    rng = np.random.RandomState(12)
+    cases = [((rng.rand(19, 23, 3) * 255).astype(np.uint8), dict(tile=0, pre_pad=3)),
+             ((rng.rand(21, 18, 3) * 255).astype(np.uint8), dict(tile=8, tile_pad=3, pre_pad=0)),
+             ((rng.rand(17, 13) * 65535).astype(np.uint16), dict(tile=0, pre_pad=0)),
+             ((rng.rand(14, 15, 4) * 255).astype(np.uint8), dict(tile=0, pre_pad=1)),
+             ((rng.rand(11, 12, 4) * 65535).astype(np.uint16), dict(tile=0, pre_pad=0, _alpha='bilinear')),
+             (rng.rand(10, 9, 3).astype(np.float32) * 300, dict(tile=0, pre_pad=0)),
+             (rng.rand(10, 9).astype(np.float64), dict(tile=0, pre_pad=0))]
+    for img, kw in cases:
+        kw = dict(kw)
+        alpha = kw.pop('_alpha', 'realesrgan')
+        r = sra.RealESRGANer(scale=4, model_path=None, model=net, half=half, **kw)
+        out, mode = r.enhance(img, alpha_upsampler=alpha)
+        sixteen = np.max(img) > 256
+        ref = r._enhance_host(img, sixteen, 65535 if sixteen else 255, mode, alpha)
+        assert out.dtype == ref.dtype and out.shape == ref.shape, (img.shape, img.dtype)
+        assert np.array_equal(out, ref), (img.shape, img.dtype, int(np.abs(out.astype(np.int64) - ref.astype(np.int64)).max()))
+    net.compute_dtype = None
+
+
 def test_cpu_tensor_is_refused(sra):
     net = sra.RRDBNet(3, 3, 4, 8, 1, 4)
     with pytest.raises(RuntimeError):
