@@ -369,8 +369,11 @@ def test_rgb_network_train_step_moves_every_parameter(sra):
     FlatAdam step must change the parameters (round-2 advisor finding: it silently did nothing)."""
     torch.manual_seed(0)
     net = sra.replace_conv_with_fdconv(sra.RRDBNet(3, 3, 4, 64, 1, 32)).cuda().train()
-    wf = torch.from_numpy(gp.image_input((2, 3, 16, 16), seed=440)).cuda()
-    srt = torch.from_numpy(gp.image_input((2, 3, 64, 64), seed=441)).cuda()
+    # four samples of different level: BatchNorm over a batch of nearly equal pooled vectors is ill-conditioned (see
+    # test_rrdbnet_train_step_vs_reference)
+    sc = torch.linspace(0.1, 2.0, 4).view(4, 1, 1, 1)
+    wf = (torch.from_numpy(gp.image_input((4, 3, 16, 16), seed=440)) * sc + (sc - 1) * 0.3).cuda()
+    srt = torch.from_numpy(gp.image_input((4, 3, 64, 64), seed=441)).cuda()
     pred = net(wf)
     loss = sra.head.resize_l1_loss(pred, srt)
     loss.backward()
@@ -457,3 +460,50 @@ def test_mixed_precision_training_step_tracks_the_float32_step(sra):
           'large parameter' % (psnr, lb, l32, cos_all, worst))
     assert psnr > 40.0 and abs(lb - l32) < 2e-3 * max(1.0, abs(l32))
     assert cos_all > 0.995 and worst > 0.95  # measured 0.99982 / 0.966
+
+
+def test_config3_shape_training_steps(sra):
+    """BASELINE configs[3] at its stated size (round-2 verdict: only the builder's bench ever ran it): RRDBNet-FDConv
+    (1,1,64,23,32), 32 HR crops of 256x256 per GPU (LR 64x64), mixed precision, train.FlatAdam -- three steps with a finite,
+    decreasing loss; and on a 4-sample slice of the same batch the mixed-precision gradient against the float32 step
+    (the parity path, pinned to the reference's gradients above): cosine over all parameters."""
+    torch.manual_seed(1234)
+    net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 23, 32)).cuda().train()
+    start = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    B, hr = 32, 256
+    g = torch.Generator().manual_seed(4321)
+    srt = torch.rand(B, 1, hr, hr, generator=g) * torch.linspace(0.3, 1.0, B).view(B, 1, 1, 1)
+    srt = torch.nn.functional.avg_pool2d(srt, 3, 1, 1)           # some spatial correlation
+    wf = torch.nn.functional.avg_pool2d(srt, 4)
+    srt, wf = srt.cuda(), wf.cuda()
+    grads = {}
+    pick = [0, 10, 21, 31]  # four crops of different brightness: BatchNorm over nearly equal samples is ill-conditioned
+    for name, cdt in (('f32', None), ('bf16', torch.bfloat16)):
+        net.load_state_dict(start)
+        net.train()
+        net.compute_dtype = cdt
+        net.zero_grad(set_to_none=True)
+        pred = net(wf[pick])
+        loss = sra.head.resize_l1_loss(pred, srt[pick])
+        loss.backward()
+        grads[name] = (loss.item(), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double())
+    (l32, g32), (lb, gb) = grads['f32'], grads['bf16']
+    cos = float((g32 * gb).sum() / (g32.norm() * gb.norm()))
+    assert torch.isfinite(g32).all() and torch.isfinite(gb).all()
+    # the full-size steps
+    net.load_state_dict(start)
+    net.train()
+    net.compute_dtype = torch.bfloat16
+    opt = sra.train.FlatAdam(net.parameters(), lr=1e-4)
+    torch.cuda.reset_peak_memory_stats()
+    losses = [float(sra.train.train_step(net, opt, wf, srt)) for _ in range(3)]
+    print('configs[3] shape: 4-sample slice loss f32 %.5f / bf16 %.5f, gradient cosine %.5f; 3 steps at B=32: %s, peak %.1f GB'
+          % (l32, lb, cos, ' '.join('%.5f' % v for v in losses), torch.cuda.max_memory_allocated() / 1e9))
+    # A random-init 23-block network sits at the edge of chaos (tools/diag_train.py: prediction PSNR bf16-vs-fp32 56 dB at
+    # 1-8 blocks, 48 dB at 23 in train mode, 12 dB in eval mode on the same data; gradient norms up to 4e5), so the bars
+    # are those of a well-conditioned but deep network, and the loss must end below its start (Adam at 1e-4 on gradients
+    # of norm ~20 need not descend monotonically)
+    assert abs(lb - l32) < 1e-2 * max(1.0, abs(l32))
+    assert cos > 0.98
+    assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0]
+    assert int(net.body[22].rdb3.conv5.KSM_Global.bn.num_batches_tracked) >= 3
