@@ -271,6 +271,33 @@ int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, const float
                           sr_view dx_direct, sr_view a2, sr_view a4, sr_view a8, const float* dpooled, int dpooled_ld,
                           sr_view dx_out, float* dgate_w, float* dgate_b, void* stream);
 
+/* backward of the weight path: gradients of sr_fdconv_weightgen's output with respect to every parameter it reads and to
+ * the pooled means.  The reference obtains them from torch autograd through KSM_Global (FDConv.py:245-258), KSM_Local
+ * (FDConv.py:302-321), the spectral scatter + irfft2 (FDConv.py:661-684) and the aggregation (FDConv.py:692-697).
+ *   dw     [B][9][cout][cin] float: gradient with respect to the per-sample weights (sr_conv3x3_wgrad, per_sample != 0)
+ *   mods   the workspace sr_fdconv_weightgen left behind for the same B, pooled and parameters (ca | ln | fa | sa | ka)
+ *   gmap   uint8 (3 cout, 3 cin / 2 + 1) frequency-group ids, alpha as for sr_fdconv_basis; lp->basis must be current
+ *   train  as in the forward call (BatchNorm on batch statistics; the running statistics are NOT touched here)
+ *   grads  one float32 output per parameter, each OVERWRITTEN, shapes of the state_dict entries:
+ *          dft_weight (3 cout, 3 cin / 2 + 1, 2) -- by linearity  d dft[r][c] = alpha w_c / (9 cout cin) rfft2(S_G(r,c))[r][c]
+ *          with S_g = sum_b ka[b][g] dA[b] (adjoint of the C2R transform, w_c = 1 on the self-conjugate columns, else 2)
+ *   dpooled (B, dpooled_ld) float, OVERWRITTEN: gradient with respect to the pooled means (both KSM branches).
+ * Sums over the batch inside wp_elem / wp_ln are float atomics (last bits vary from run to run). */
+typedef struct {
+    float* dft_weight;
+    float* fc_w;
+    float *bn_w, *bn_b;
+    float *relu_s, *relu_b;
+    float *ch_w, *ch_b, *fl_w, *fl_b, *sp_w, *sp_b, *kn_w, *kn_b;
+    float* loc_w;
+    float *ln_w, *ln_b;
+} sr_weight_path_grads;
+size_t sr_fdconv_weightgen_backward_workspace_bytes(int B, int cin, int cout);
+int sr_fdconv_weightgen_backward(int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, int train, const float* mods,
+                                 const float* dft_weight, const uint8_t* gmap, float alpha, const float* dw,
+                                 const sr_weight_path_grads* grads, float* dpooled, int dpooled_ld, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* ---- whole network (RRDBNet.forward) ------------------------------------------------------- */
 typedef struct sr_rrdbnet sr_rrdbnet;
 int sr_rrdbnet_create(int num_in_ch, int num_out_ch, int scale, int num_feat, int num_block, int num_grow_ch,

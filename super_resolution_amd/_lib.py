@@ -43,6 +43,14 @@ class LayerParams(C.Structure):
                 ('loc_w', C.c_void_p), ('ln_w', C.c_void_p), ('ln_b', C.c_void_p), ('wpacked_lo_off', C.c_int64)]
 
 
+WEIGHT_PATH_GRADS = ('dft_weight', 'fc_w', 'bn_w', 'bn_b', 'relu_s', 'relu_b', 'ch_w', 'ch_b', 'fl_w', 'fl_b', 'sp_w', 'sp_b', 'kn_w',
+                     'kn_b', 'loc_w', 'ln_w', 'ln_b')
+
+
+class WeightPathGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in WEIGHT_PATH_GRADS]
+
+
 class GateConsumer(C.Structure):
     _fields_ = [('w', C.c_void_p * 3), ('b', C.c_void_p * 3), ('logits', C.c_void_p), ('gates', C.c_void_p), ('first', C.c_int32)]
 
@@ -72,6 +80,10 @@ _SIGS = {
     'sr_fdconv_weightgen_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_fdconv_weightgen': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_int, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_fdconv_weightgen_backward_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'sr_fdconv_weightgen_backward': (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_float, C.c_void_p, C.POINTER(WeightPathGrads), C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_conv_weight_transpose': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_conv3x3_wgrad': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, View, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['layout.hip', 'fbm.hip', 'fbm_fast.hip', 'fbm_mfma.hip', 'gates.hip', 'weightgen.hip', 'conv.hip', 'net.hip', 'head.hip', 'train.hip']
+SOURCES = ['layout.hip', 'fbm.hip', 'fbm_fast.hip', 'fbm_mfma.hip', 'gates.hip', 'weightgen.hip', 'weightgen_bwd.hip', 'conv.hip', 'net.hip', 'head.hip', 'train.hip']
 OUT = os.path.join(HERE, 'libsr_amd.so')
 
 
@@ -27,9 +27,14 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(HERE, '..', 'include', 'sr_amd.h')]
+    newest_header = max(os.path.getmtime(h) for h in headers)
     for s in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(o)
+        src = os.path.join(CSRC, s)
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(src), newest_header):
+            continue  # object is newer than its source and every header
         cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fno-signed-zeros', '-fPIC', '-Wall', '-Wno-unused-result', '-c',
                os.path.join(CSRC, s), '-o', o]
         procs.append((cmd, subprocess.Popen(cmd)))

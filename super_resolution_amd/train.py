@@ -17,11 +17,9 @@ bfloat16 inputs -- or `net.compute_dtype = torch.bfloat16` with float32 data -- 
 their gradients in bf16 on the matrix cores (MFMA convolution forward and operand gradient with split hi + lo weights,
 MFMA low-pass), parameters, weight gradients, gates and every reduction in float32.
 
-Two things stay on torch autograd (device tensors, no CPU path):
-  * the SMALL weight path -- pooled (B, Cin) -> W_b (B, 9, Cout, Cin): KSM_Global / KSM_Local / spectral scatter + irfft2
-    (a few hundred KB per layer).  Its backward is torch's, on a torch restatement (`dynamic_weight`) that is recomputed
-    in backward and fed the HIP weight gradient;
-  * the glue between layers in `rrdbnet_train_forward` (LeakyReLU, channel concat, residual adds, nearest 2x).
+The weight path -- pooled (B, Cin) -> W_b (B, 9, Cout, Cin): KSM_Global / KSM_Local / spectral scatter + irfft2 -- has a
+hand-written backward too (`sr_fdconv_weightgen_backward`: no torch.fft, no F.batch_norm; its torch restatement lives in
+tests/weight_path_torch.py as a checker only).
 Data-parallel training: `allreduce_gradients` (bucketed all-reduce of the parameter gradients over torch.distributed --
 RCCL on the GPUs; BatchNorm statistics stay local to a rank, as under the reference's nn.DataParallel,
 train/train_realESRGAN_fdconv_OST_1.py:238-246).
@@ -38,93 +36,47 @@ from .fdconv import FDConv
 BN_EPS = 1e-5
 
 
-# ------------------------------------------------------------------------------------------------------------------
-# the small weight path as torch ops (backward glue)
-# ------------------------------------------------------------------------------------------------------------------
-def _group_onehot(m):
-    """(kernel_num, bins) float one-hot of the frequency-group id of every rfft2 bin: ka[b, G(r, c)] = ka @ onehot, a
-    matmul whose backward is a matmul (indexing with the group map goes back through an index_put)."""
-    gmap = m.group_map()
-    key = (gmap.data_ptr(), gmap.device)
-    hit = m._sr_cache.get('onehot')
-    if hit is None or hit[0] != key:
-        oh = F.one_hot(gmap.view(-1).long(), m.kernel_num).t().to(torch.float32).contiguous()
-        m._sr_cache['onehot'] = hit = (key, oh)
-    return hit[1]
+# struct field of sr_weight_path_grads -> parameter name inside an FDConv module (same order as L.WEIGHT_PATH_GRADS)
+_WP_FIELDS = (('dft_weight', 'dft_weight'), ('fc_w', 'KSM_Global.fc.weight'), ('bn_w', 'KSM_Global.bn.weight'), ('bn_b', 'KSM_Global.bn.bias'),
+              ('relu_s', 'KSM_Global.relu.scale'), ('relu_b', 'KSM_Global.relu.bias'), ('ch_w', 'KSM_Global.channel_fc.weight'),
+              ('ch_b', 'KSM_Global.channel_fc.bias'), ('fl_w', 'KSM_Global.filter_fc.weight'), ('fl_b', 'KSM_Global.filter_fc.bias'),
+              ('sp_w', 'KSM_Global.spatial_fc.weight'), ('sp_b', 'KSM_Global.spatial_fc.bias'), ('kn_w', 'KSM_Global.kernel_fc.weight'),
+              ('kn_b', 'KSM_Global.kernel_fc.bias'), ('loc_w', 'KSM_Local.conv.weight'), ('ln_w', 'KSM_Local.norm.weight'),
+              ('ln_b', 'KSM_Local.norm.bias'))
+assert tuple(f for f, _ in _WP_FIELDS) == L.WEIGHT_PATH_GRADS
 
 
-class _GroupLookup(torch.autograd.Function):
-    """per_bin[b, j] = ka[b, G(j)] as a matmul with the one-hot map; its gradient wrt ka is a per-group sum, taken over the
-    bins sorted by group (the matmul form, (B x bins) @ (bins x kernel_num), is a 55k-deep skinny GEMM: 63 us)."""
-
-    @staticmethod
-    def forward(ctx, ka, onehot, order):
-        ctx.save_for_backward(order)
-        ctx.kn = onehot.shape[0]
-        return ka @ onehot
-
-    @staticmethod
-    def backward(ctx, g):
-        (order,) = ctx.saved_tensors
-        return g.index_select(1, order).view(g.shape[0], ctx.kn, -1).sum(2), None, None
-
-
-def _group_order(m):
-    """bin indices sorted by group id (every group holds the same number of bins: FDConv.py:604-631), cached."""
-    gmap = m.group_map()
-    key = (gmap.data_ptr(), gmap.device)
-    hit = m._sr_cache.get('order')
-    if hit is None or hit[0] != key:
-        flat = gmap.view(-1).long()
-        if not bool((torch.bincount(flat, minlength=m.kernel_num) == flat.numel() // m.kernel_num).all()):
-            raise ValueError('FDConv: frequency groups of unequal size')
-        m._sr_cache['order'] = hit = (key, torch.sort(flat, stable=True).indices)
-    return hit[1]
-
-
-def dynamic_weight(pooled, m, training):
-    """W_b (B, 9, Cout, Cin) of FDConv `m` from the pooled means (B, Cin): FDConv.py:643-652, 661-697.
-
-    Same result as `sr_fdconv_weightgen`, built from differentiable torch ops; used only to back-propagate the weight
-    gradient into the KSM / spectrum parameters and the pooled means.  A training step spends its host time here (349
-    layers, every op a launch and an autograd node), so the formulation keeps the op count low: fused batch norm, the
-    four attention heads as one linear + one sigmoid, the group lookup as a matmul, and every constant factor (the four
-    2 x sigmoid scalings, alpha and 2 / kernel_num) folded into the spectrum."""
-    g, loc = m.KSM_Global, m.KSM_Local
-    B, cin = pooled.shape
-    cout, kn = m.out_channels, m.kernel_num
-    z = F.linear(pooled, g.fc.weight.flatten(1))
-    if training:
-        z = F.batch_norm(z, None, None, g.bn.weight, g.bn.bias, True, 0.0, BN_EPS)
-    else:
-        z = F.batch_norm(z, g.bn.running_mean, g.bn.running_var, g.bn.weight, g.bn.bias, False, 0.0, BN_EPS)
-    r = torch.relu(z)
-    a = torch.addcmul(g.relu.bias, r * g.relu.scale, r)                 # StarReLU: s relu(z)^2 + b
-    heads = (g.channel_fc, g.filter_fc, g.spatial_fc, g.kernel_fc)
-    hw = torch.cat([h.weight.flatten(1) for h in heads], 0)
-    hb = torch.cat([h.bias for h in heads], 0)
-    ca, fa, sa, ka = torch.sigmoid(F.linear(a, hw, hb)).split([cin, cout, 9, kn], 1)   # without their factors 2, 2, 2, 2 / kn
-    ln = F.layer_norm(pooled, (cin,), loc.norm.weight, loc.norm.bias, 1e-5)
-    # KSM_Local's k-tap conv along the channel axis as a matmul over unfolded windows (a 1 -> Cout*9 channel conv1d of length
-    # Cin lands on MIOpen's naive kernels in backward: 0.5 ms per call)
-    k = loc.conv.kernel_size[0]
-    lnu = F.pad(ln, ((k - 1) // 2, (k - 1) // 2)).unfold(1, k, 1)                        # (B, Cin, k)
-    hr = torch.sigmoid(lnu @ loc.conv.weight.view(cout * 9, k).t())                      # (B, Cin, Cout*9), without its 2
-    # spectrum scaled per frequency group and sample, inverse real 2-D DFT, (3Cout, 3Cin) -> [o, u, i, v]
-    scale = 16.0 * float(m.alpha) * 2.0 / kn
-    spec = torch.view_as_complex(m.dft_weight[0]) * scale                                # (3Cout, 3Cin/2+1)
-    per_bin = _GroupLookup.apply(ka, _group_onehot(m), _group_order(m)).view(B, *spec.shape)  # ka[b, G(r, c)]
-    adaptive = torch.fft.irfft2(spec * per_bin, s=(3 * cout, 3 * cin))                   # (B, 3Cout, 3Cin)
-    adaptive = adaptive.view(B, cout, 3, cin, 3).permute(0, 2, 4, 1, 3).reshape(B, 9, cout, cin)
-    mod = (sa[:, :, None] * fa[:, None, :])[:, :, :, None] * ca[:, None, None, :]        # (B, 9, Cout, Cin)
-    return mod * hr.view(B, cin, cout, 9).permute(0, 3, 2, 1) * adaptive
-
-
-_WEIGHT_PATH = ('dft_weight', 'KSM_Global.fc.weight', 'KSM_Global.bn.weight', 'KSM_Global.bn.bias', 'KSM_Global.relu.scale',
-                'KSM_Global.relu.bias', 'KSM_Global.channel_fc.weight', 'KSM_Global.channel_fc.bias',
-                'KSM_Global.filter_fc.weight', 'KSM_Global.filter_fc.bias', 'KSM_Global.spatial_fc.weight',
-                'KSM_Global.spatial_fc.bias', 'KSM_Global.kernel_fc.weight', 'KSM_Global.kernel_fc.bias',
-                'KSM_Local.conv.weight', 'KSM_Local.norm.weight', 'KSM_Local.norm.bias')
+def weight_path_backward(m, lp, pooled, pooled_ld, mods, dw, training, dpooled=None, dpooled_ld=None):
+    """dW_b (B, 9, Cout, Cin) float32 -> ({parameter name: gradient}, dpooled (B, Cin)) for the weight path of FDConv `m`
+    (KSM_Global, KSM_Local, spectrum), one call into libsr_amd (`sr_fdconv_weightgen_backward`: hand-written kernels, no
+    torch operator).  `mods` is the workspace the forward's sr_fdconv_weightgen left behind; `pooled` may be a wider
+    buffer (pooled_ld floats per sample).  dpooled: optional destination (B rows of dpooled_ld floats), else allocated."""
+    lib, dev = L.lib(), dw.device
+    B = dw.shape[0]
+    cin, cout = m.in_channels, m.out_channels
+    hit = m._sr_cache.get('wp_layout')
+    if hit is None:
+        params = _named_params(m)[2]
+        shapes = [tuple(params[n].shape) for _, n in _WP_FIELDS]
+        sizes = [max(1, int(torch.Size(sh).numel())) for sh in shapes]
+        m._sr_cache['wp_layout'] = hit = (shapes, sizes, sum(sizes))
+    shapes, sizes, total = hit
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    pieces = flat.split(sizes)
+    gs = L.WeightPathGrads()
+    out = {}
+    for (field, name), piece, shape in zip(_WP_FIELDS, pieces, shapes):
+        setattr(gs, field, piece.data_ptr())
+        out[name] = piece.view(shape)
+    if dpooled is None:
+        dpooled = torch.empty(B, cin, dtype=torch.float32, device=dev)
+        dpooled_ld = cin
+    ws = torch.empty(lib.sr_fdconv_weightgen_backward_workspace_bytes(B, cin, cout), dtype=torch.uint8, device=dev)
+    L.check(lib.sr_fdconv_weightgen_backward(B, pooled.data_ptr(), pooled_ld, C.byref(lp), int(training), mods.data_ptr(),
+                                             m.dft_weight.data_ptr(), m.group_map().data_ptr(), float(m.alpha), dw.data_ptr(),
+                                             C.byref(gs), dpooled.data_ptr(), dpooled_ld, ws.data_ptr(), ws.numel(),
+                                             L.stream_ptr(dev)), 'sr_fdconv_weightgen_backward')
+    return out, dpooled
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -279,12 +231,12 @@ class _FDConvFn(torch.autograd.Function):
             y = _unpack(yn)
         ctx.m, ctx.training = m, training
         ctx.names = _named_params(m)[0]
-        ctx.save_for_backward(xn, bands[0], bands[1], bands[2], gates, pooled, wdyn)
+        ctx.save_for_backward(xn, bands[0], bands[1], bands[2], gates, pooled, wdyn, mods)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xn, b2, b4, b8, gates, pooled, wdyn = ctx.saved_tensors
+        xn, b2, b4, b8, gates, pooled, wdyn, mods = ctx.saved_tensors
         m = ctx.m
         lib, dev = L.lib(), dy.device
         B, H, W, cin = xn.shape
@@ -323,16 +275,9 @@ class _FDConvFn(torch.autograd.Function):
                 L.check(lib.sr_fbm_lowpass(plan, code, B, L.view(src), 0, planes[0], planes[1], planes[2],
                                            None, 0, ws.data_ptr(), ws.numel(), st), 'sr_fbm_lowpass (adjoint)')
                 adj.append(out)
-            # 5. the small weight path on torch autograd: dW_b -> parameters and pooled means
-            params = _named_params(m)[2]
-            wp = [params[n] for n in _WEIGHT_PATH]
-            with torch.enable_grad():
-                pl = pooled.detach().requires_grad_(True)
-                wfull = dynamic_weight(pl, m, ctx.training)
-                got = torch.autograd.grad(wfull, [pl] + wp, dw, allow_unused=True)
-            dpooled = got[0].contiguous()
-            for n, gch in zip(_WEIGHT_PATH, got[1:]):
-                grads[n] = gch
+            # 5. the small weight path: dW_b -> parameters and pooled means (hand-written backward kernels)
+            wgrads, dpooled = weight_path_backward(m, lp, pooled, cin, mods, dw, ctx.training)
+            grads.update(wgrads)
             # 6. gate convs + assembly of the input gradient
             dxn = torch.empty_like(xn)
             if xn.dtype == torch.bfloat16 and cin % 32 == 0:

@@ -209,6 +209,46 @@ def test_input_gradient_vector_kernel_matches_scalar_kernel_bf16(sra, B, Cc, H, 
     assert (got != ref).float().mean().item() < 0.05  # a last-bit difference is rare
 
 
+# ------------------------------------------------------------------------------------------------------- weight path
+@pytest.mark.parametrize('cin,cout,B,training,pseed', [(64, 32, 4, True, 100), (64, 32, 3, False, 100), (192, 64, 2, True, 104),
+                                                       (160, 32, 5, True, 103), (64, 64, 6, False, 105)])
+def test_weight_path_backward_vs_torch_autograd(sra, cin, cout, B, training, pseed):
+    """sr_fdconv_weightgen_backward (hand-written backward of KSM_Global / KSM_Local / spectral scatter + irfft2) against
+    torch autograd through the torch restatement of the same path (tests/weight_path_torch.py, pinned to the oracle on
+    the CPU): the gradient of a random cotangent dW with respect to the pooled means and all 17 parameters."""
+    import ctypes as C
+    from super_resolution_amd import _lib as L
+    from weight_path_torch import dynamic_weight, _WEIGHT_PATH
+    lib = L.lib()
+    layer = sra.FDConv(cin, cout, kernel_size=3, stride=1, padding=1, bias=True)
+    layer.load_state_dict(t(gp.fdconv_params(cin, cout, seed=pseed)), strict=True)
+    layer = layer.cuda()
+    g = torch.Generator().manual_seed(cin + cout + B)
+    pooled = (torch.randn(B, cin, generator=g) * 0.5 + 0.2).cuda()
+    dw = torch.randn(B, 9, cout, cin, generator=g).cuda()
+    lp, _keep = layer.sr_layer_params(torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    wdyn = torch.empty(B, 9, cout, cin, device='cuda')
+    mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout), dtype=torch.uint8, device='cuda')
+    L.check(lib.sr_fdconv_weightgen(0, B, pooled.data_ptr(), cin, C.byref(lp), int(training), 0.0, wdyn.data_ptr(), None, mods.data_ptr(),
+                                    mods.numel(), st))
+    grads, dpooled = sra.train.weight_path_backward(layer, lp, pooled, cin, mods, dw, training)
+    params = dict(layer.named_parameters())
+    pl = pooled.clone().requires_grad_(True)
+    w = dynamic_weight(pl, layer, training)
+    assert (w.detach() - wdyn).abs().max().item() < 1e-5 * max(1.0, wdyn.abs().max().item())
+    ref = torch.autograd.grad(w, [pl] + [params[n] for n in _WEIGHT_PATH], dw)
+    def rel(got, want, what):  # relative to the gradient's own largest entry (float32 sums of up to 1e5 terms)
+        assert got.shape == want.shape, what
+        err, scale = (got - want).abs().max().item(), want.abs().max().item()
+        assert err <= 2e-4 * scale + 1e-9, '%s: max err %.3e of %.3e' % (what, err, scale)
+        return err / max(scale, 1e-30)
+    worst = rel(dpooled, ref[0], 'dpooled')
+    for n, r in zip(_WEIGHT_PATH, ref[1:]):
+        worst = max(worst, rel(grads[n], r, 'grad ' + n))
+    print('weight-path backward %d->%d B=%d %s: worst relative error %.2e' % (cin, cout, B, 'train' if training else 'eval', worst))
+
+
 # ------------------------------------------------------------------------------------------------------- layers
 @pytest.mark.parametrize('tag,cin,cout,B,h,w,pseed', [('c64_32', 64, 32, 4, 20, 24, 100), ('c192_64', 192, 64, 2, 16, 12, 104)])
 def test_fdconv_train_mode_gradients_vs_reference(sra, golden_r2, tag, cin, cout, B, h, w, pseed):

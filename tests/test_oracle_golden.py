@@ -180,9 +180,10 @@ def test_oracle_train_mode_gradients_vs_reference(golden_r2, tag, cin, cout, B, 
 
 
 def test_training_glue_dynamic_weight_matches_oracle():
-    """super_resolution_amd.train.dynamic_weight (the torch restatement of the small weight path that the HIP backward
-    hands its weight gradient to) against the oracle's weights, eval and train mode, on the CPU."""
+    """tests/weight_path_torch.dynamic_weight (the torch restatement of the small weight path that the GPU tests hold
+    sr_fdconv_weightgen_backward against) against the oracle's weights, eval and train mode, on the CPU."""
     import super_resolution_amd as sra
+    from weight_path_torch import dynamic_weight
     for cin, cout, seed in ((64, 32, 100), (192, 64, 104)):
         sd = t(gp.fdconv_params(cin, cout, seed=seed))
         m = sra.FDConv(cin, cout, kernel_size=3, stride=1, padding=1, bias=True)
@@ -192,6 +193,6 @@ def test_training_glue_dynamic_weight_matches_oracle():
             want = {}
             fr.fdconv_forward(x, sd, training=training, want=want)
             with torch.no_grad():
-                w = sra.train.dynamic_weight(want['pooled'], m, training)
+                w = dynamic_weight(want['pooled'], m, training)
             ref = want['weight'].permute(0, 3, 4, 1, 2).reshape(3, 9, cout, cin)
             assert (w - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
