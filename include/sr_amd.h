@@ -259,17 +259,35 @@ int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat* in, const 
  *   dlogits (B,H,W,4) float = {dz1, dz2, dz3, 0}: gradients wrt the gate-conv outputs z_k (g_k = 2 sigmoid(z_k)),
  *   dz1 = sum_c da (x - L2) * g1 (1 - g1/2), dz2 with (L2 - L4), dz3 with (L4 - L8). */
 int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_view l2, sr_view l4, sr_view l8, const float* gates, sr_view da,
-                    sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, void* stream);
+                    sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, int accumulate, void* dlogits_bf16x32,
+                    void* stream);
+/* accumulate != 0: the four branch gradients are ADDED to what dx / dl2 / dl4 / dl8 hold -- a tensor of a dense block feeds
+ * several layers (torch.cat in basicsr's ResidualDenseBlock), the consumers' branch gradients are summed in place and the
+ * adjoint low-pass then runs once per produced tensor on the sums (the low-pass is linear).
+ * dlogits_bf16x32 (may be NULL): also receives the logit gradients as a (B,H,W,32) bf16 tensor {dz1, dz2, dz3, 0 ...}: the
+ * dy operand with which sr_conv3x3_wgrad (cout = 32) computes the gate convs' weight and bias gradients on the matrix cores. */
 /* backward of the three gate convs (FDConv.py:460-461) and assembly of the layer's input gradient:
  *   dgate_w [3][cin][9], dgate_b [3] (float32, OVERWRITTEN; same atomics remark as sr_conv3x3_wgrad); both NULL: not
  *   computed (the bf16 training path gets them from sr_conv3x3_wgrad with the logit gradients in the place of dy)
  *   dx_out = dx_direct + a2 + a4 + a8 + conv3x3^T(dlogits; gate_w) + dpooled[b][c] / (H W)
  * a_k = sr_fbm_lowpass plane k of dl_k (the box low-pass is self-adjoint: a real symmetric mask between a unitary
  * transform pair); dpooled (B, dpooled_ld) float or NULL: gradient wrt the pooled means (F.adaptive_avg_pool2d at
- * FDConv.py:643) that the weight path's backward returns.  dx_out may alias dx_direct. */
+ * FDConv.py:643) that the weight path's backward returns.  dx_out may alias dx_direct.
+ * a2, a4, a8 with p == NULL (all three): those terms are left out (a tensor with several consumers collects them once,
+ * after its last consumer, through sr_grad_combine). */
 int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, const float* dlogits, const sr_layer_params* lp,
                           sr_view dx_direct, sr_view a2, sr_view a4, sr_view a8, const float* dpooled, int dpooled_ld,
                           sr_view dx_out, float* dgate_w, float* dgate_b, void* stream);
+
+/* out = mask * sum_j scales[j] * terms[j]  over (B,H,W,C) views, nterms <= 8;  mask = 1 where act > 0, else `slope`
+ * (act.p == NULL: no mask).  The sum of a tensor's gradient contributions -- direct branch, adjoint low-pass planes,
+ * residual paths (x5 * 0.2 + x, out * 0.2 + x of basicsr's RDB / RRDB) -- with the backward of the LeakyReLU(0.2) that
+ * produced the tensor folded in (autograd's AddBackward / LeakyReluBackward nodes in the reference). */
+int sr_grad_combine(int dtype, int B, int H, int W, int C, int nterms, const sr_view* terms, const float* scales, sr_view act,
+                    float slope, sr_view out, void* stream);
+/* adjoint == 0: dst (B,2Hs,2Ws,C) = F.interpolate(src (B,Hs,Ws,C), scale_factor=2, mode='nearest') (RRDBNet.forward);
+ * adjoint != 0: dst (B,Hs,Ws,C) = 2 x 2 sums of src (B,2Hs,2Ws,C) (its backward). */
+int sr_upsample2x(int dtype, int B, int Hs, int Ws, int C, sr_view src, sr_view dst, int adjoint, void* stream);
 
 /* backward of the weight path: gradients of sr_fdconv_weightgen's output with respect to every parameter it reads and to
  * the pooled means.  The reference obtains them from torch autograd through KSM_Global (FDConv.py:245-258), KSM_Local

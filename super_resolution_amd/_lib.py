@@ -88,7 +88,10 @@ _SIGS = {
     'sr_conv3x3_wgrad': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, View, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_fbm_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, View, View, View, C.c_void_p, View, View, View, View,
-                                  View, C.c_void_p, C.c_void_p]),
+                                  View, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'sr_grad_combine': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(View), C.POINTER(C.c_float), View,
+                                  C.c_float, View, C.c_void_p]),
+    'sr_upsample2x': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, View, View, C.c_int, C.c_void_p]),
     'sr_fbm_gates_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, C.c_void_p, C.POINTER(LayerParams), View, View,
                                         View, View, C.c_void_p, C.c_int, View, C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_conv3x3': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, C.c_void_p, C.c_long, C.c_long,

@@ -354,7 +354,7 @@ __device__ __forceinline__ float wsum(float v) {
 template <typename T>
 __global__ __launch_bounds__(256) void fbm_backward_kernel(long total_pix, long npix, int C, View x, View l2, View l4, View l8,
                                                            const float* __restrict__ gates, View da, View dx, View dl2, View dl4,
-                                                           View dl8, float* __restrict__ dlogits) {
+                                                           View dl8, float* __restrict__ dlogits, int acc, bf16_t* __restrict__ dzpad) {
     const int lane = threadIdx.x & 63;
     const long wave0 = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
@@ -373,18 +373,23 @@ __global__ __launch_bounds__(256) void fbm_backward_kernel(long total_pix, long 
             s1 += d * (xv - v2);
             s2 += d * (v2 - v4);
             s3 += d * (v4 - v8);
-            Elem<T>::st((T*)dx.p + voff(dx, b, p, c), g.x * d);
-            Elem<T>::st((T*)dl2.p + voff(dl2, b, p, c), c1 * d);
-            Elem<T>::st((T*)dl4.p + voff(dl4, b, p, c), c2 * d);
-            Elem<T>::st((T*)dl8.p + voff(dl8, b, p, c), c3 * d);
+            T* o0 = (T*)dx.p + voff(dx, b, p, c);
+            T* o2 = (T*)dl2.p + voff(dl2, b, p, c);
+            T* o4 = (T*)dl4.p + voff(dl4, b, p, c);
+            T* o8 = (T*)dl8.p + voff(dl8, b, p, c);
+            Elem<T>::st(o0, g.x * d + (acc ? Elem<T>::ld(o0) : 0.f));
+            Elem<T>::st(o2, c1 * d + (acc ? Elem<T>::ld(o2) : 0.f));
+            Elem<T>::st(o4, c2 * d + (acc ? Elem<T>::ld(o4) : 0.f));
+            Elem<T>::st(o8, c3 * d + (acc ? Elem<T>::ld(o8) : 0.f));
         }
         s1 = wsum(s1);
         s2 = wsum(s2);
         s3 = wsum(s3);
         // g = 2 sigmoid(z)  ->  dg/dz = g (1 - g/2)
-        if (lane == 0)
-            ((float4*)dlogits)[pg] = make_float4(s1 * g.x * (1.0f - 0.5f * g.x), s2 * g.y * (1.0f - 0.5f * g.y),
-                                                 s3 * g.z * (1.0f - 0.5f * g.z), 0.f);
+        const float z1 = s1 * g.x * (1.0f - 0.5f * g.x), z2 = s2 * g.y * (1.0f - 0.5f * g.y), z3 = s3 * g.z * (1.0f - 0.5f * g.z);
+        if (lane == 0) ((float4*)dlogits)[pg] = make_float4(z1, z2, z3, 0.f);
+        if (dzpad && lane < 4)  // the same three values as a 32-channel bf16 pixel (zeros beyond): dy operand of the gate-conv weight gradient
+            ((uint4*)dzpad)[pg * 4 + lane] = lane == 0 ? make_uint4(pack2(z1, z2), pack2(z3, 0.f), 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -394,7 +399,8 @@ __global__ __launch_bounds__(256) void fbm_backward_kernel(long total_pix, long 
 template <int PC>
 __global__ __launch_bounds__(256) void fbm_backward_vec_kernel(long total_pix, long npix, int C, View x, View l2, View l4, View l8,
                                                                const float* __restrict__ gates, View da, View dx, View dl2,
-                                                               View dl4, View dl8, float* __restrict__ dlogits) {
+                                                               View dl4, View dl8, float* __restrict__ dlogits, int acc,
+                                                               bf16_t* __restrict__ dzpad) {
     constexpr int PPW = 64 / PC;  // pixels per wavefront
     const int lane = threadIdx.x & 63, sub = lane & (PC - 1);
     const long wave0 = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -417,16 +423,28 @@ __global__ __launch_bounds__(256) void fbm_backward_vec_kernel(long total_pix, l
             const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w}, w2[4] = {a2.x, a2.y, a2.z, a2.w},
                            w4[4] = {a4.x, a4.y, a4.z, a4.w}, w8[4] = {a8.x, a8.y, a8.z, a8.w};
             uint32_t o0[4], o2[4], o4[4], o8[4];
+            // accumulate mode (a tensor with several consumers: the consumers' branch gradients are summed in place)
+            uint32_t p0[4] = {0u, 0u, 0u, 0u}, p2[4] = {0u, 0u, 0u, 0u}, p4[4] = {0u, 0u, 0u, 0u}, p8[4] = {0u, 0u, 0u, 0u};
+            if (acc) {
+                const uint4 q0 = *(const uint4*)((const bf16_t*)dx.p + voff(dx, b, p, sub * 8));
+                const uint4 q2 = *(const uint4*)((const bf16_t*)dl2.p + voff(dl2, b, p, sub * 8));
+                const uint4 q4 = *(const uint4*)((const bf16_t*)dl4.p + voff(dl4, b, p, sub * 8));
+                const uint4 q8 = *(const uint4*)((const bf16_t*)dl8.p + voff(dl8, b, p, sub * 8));
+                p0[0] = q0.x; p0[1] = q0.y; p0[2] = q0.z; p0[3] = q0.w;
+                p2[0] = q2.x; p2[1] = q2.y; p2[2] = q2.z; p2[3] = q2.w;
+                p4[0] = q4.x; p4[1] = q4.y; p4[2] = q4.z; p4[3] = q4.w;
+                p8[0] = q8.x; p8[1] = q8.y; p8[2] = q8.z; p8[3] = q8.w;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float d0 = lo_f(dw[i]), d1 = hi_f(dw[i]);
                 s1 += d0 * (lo_f(xw[i]) - lo_f(w2[i])) + d1 * (hi_f(xw[i]) - hi_f(w2[i]));
                 s2 += d0 * (lo_f(w2[i]) - lo_f(w4[i])) + d1 * (hi_f(w2[i]) - hi_f(w4[i]));
                 s3 += d0 * (lo_f(w4[i]) - lo_f(w8[i])) + d1 * (hi_f(w4[i]) - hi_f(w8[i]));
-                o0[i] = pack2(g.x * d0, g.x * d1);
-                o2[i] = pack2(c1 * d0, c1 * d1);
-                o4[i] = pack2(c2 * d0, c2 * d1);
-                o8[i] = pack2(c3 * d0, c3 * d1);
+                o0[i] = pack2(g.x * d0 + lo_f(p0[i]), g.x * d1 + hi_f(p0[i]));
+                o2[i] = pack2(c1 * d0 + lo_f(p2[i]), c1 * d1 + hi_f(p2[i]));
+                o4[i] = pack2(c2 * d0 + lo_f(p4[i]), c2 * d1 + hi_f(p4[i]));
+                o8[i] = pack2(c3 * d0 + lo_f(p8[i]), c3 * d1 + hi_f(p8[i]));
             }
             *(uint4*)((bf16_t*)dx.p + voff(dx, b, p, sub * 8)) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
             *(uint4*)((bf16_t*)dl2.p + voff(dl2, b, p, sub * 8)) = make_uint4(o2[0], o2[1], o2[2], o2[3]);
@@ -439,9 +457,10 @@ __global__ __launch_bounds__(256) void fbm_backward_vec_kernel(long total_pix, l
             s2 += __shfl_xor(s2, m, 64);
             s3 += __shfl_xor(s3, m, 64);
         }
-        if (sub == 0 && pg < total_pix)
-            ((float4*)dlogits)[pg] = make_float4(s1 * g.x * (1.0f - 0.5f * g.x), s2 * g.y * (1.0f - 0.5f * g.y),
-                                                 s3 * g.z * (1.0f - 0.5f * g.z), 0.f);
+        const float z1 = s1 * g.x * (1.0f - 0.5f * g.x), z2 = s2 * g.y * (1.0f - 0.5f * g.y), z3 = s3 * g.z * (1.0f - 0.5f * g.z);
+        if (sub == 0 && pg < total_pix) ((float4*)dlogits)[pg] = make_float4(z1, z2, z3, 0.f);
+        if (dzpad && sub < 4 && pg < total_pix)  // PC >= 8 lanes per pixel: lanes 0..3 write the 64-byte padded bf16 pixel
+            ((uint4*)dzpad)[pg * 4 + sub] = sub == 0 ? make_uint4(pack2(z1, z2), pack2(z3, 0.f), 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -473,8 +492,10 @@ __global__ __launch_bounds__(256) void input_grad_kernel(int B, int H, int W, in
         const int b = (int)(pg / npix);
         const long p = pg - (long)b * npix;
         const int h = (int)(p / W), w = (int)(p - (long)h * W);
-        float v = Elem<T>::ld((const T*)dxd.p + voff(dxd, b, p, cc)) + Elem<T>::ld((const T*)a2.p + voff(a2, b, p, cc)) +
-                  Elem<T>::ld((const T*)a4.p + voff(a4, b, p, cc)) + Elem<T>::ld((const T*)a8.p + voff(a8, b, p, cc));
+        float v = Elem<T>::ld((const T*)dxd.p + voff(dxd, b, p, cc));
+        if (a2.p)  // (all three or none: checked on the host)
+            v += Elem<T>::ld((const T*)a2.p + voff(a2, b, p, cc)) + Elem<T>::ld((const T*)a4.p + voff(a4, b, p, cc)) +
+                 Elem<T>::ld((const T*)a8.p + voff(a8, b, p, cc));
         if (dpooled) v += dpooled[(long)b * dpooled_ld + cc] * inv;
         float gsum = 0.f;
 #pragma unroll
@@ -516,10 +537,11 @@ __global__ __launch_bounds__(256) void input_grad_vec_kernel(int B, int H, int W
         const int b = (int)(pg / npix);
         const long p = pg - (long)b * npix;
         const int h = (int)(p / W), w = (int)(p - (long)h * W);
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
         const uint4 v0 = *(const uint4*)((const bf16_t*)dxd.p + voff(dxd, b, p, c0));
-        const uint4 v2 = *(const uint4*)((const bf16_t*)a2.p + voff(a2, b, p, c0));
-        const uint4 v4 = *(const uint4*)((const bf16_t*)a4.p + voff(a4, b, p, c0));
-        const uint4 v8 = *(const uint4*)((const bf16_t*)a8.p + voff(a8, b, p, c0));
+        const uint4 v2 = a2.p ? *(const uint4*)((const bf16_t*)a2.p + voff(a2, b, p, c0)) : zero4;
+        const uint4 v4 = a2.p ? *(const uint4*)((const bf16_t*)a4.p + voff(a4, b, p, c0)) : zero4;
+        const uint4 v8 = a2.p ? *(const uint4*)((const bf16_t*)a8.p + voff(a8, b, p, c0)) : zero4;
         const uint32_t w0[4] = {v0.x, v0.y, v0.z, v0.w}, w2[4] = {v2.x, v2.y, v2.z, v2.w}, w4[4] = {v4.x, v4.y, v4.z, v4.w},
                        w8[4] = {v8.x, v8.y, v8.z, v8.w};
         float acc[8];
@@ -621,6 +643,98 @@ __global__ __launch_bounds__(256) void gate_wgrad_kernel(int B, int H, int W, in
         for (int k = 0; k < 3; ++k) atomicAdd(dgb + k, bsum[k]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// elementwise pieces of the network-level backward (no torch operator between the layers):
+//   grad_combine : out = mask(act) * sum_j scale_j term_j,  mask = act > 0 ? 1 : slope  (LeakyReLU / PReLU-free backward folded
+//                  into the sum of a tensor's gradient contributions: direct branch, three adjoint low-pass planes, residuals)
+//   upsample2x   : F.interpolate(scale_factor=2, mode='nearest') of RRDBNet.forward, materialised for the training path
+//   downsum2x    : its adjoint (2 x 2 sums)
+constexpr int GC_MAX = 8;
+struct CombineArgs {
+    int n;
+    View t[GC_MAX];
+    float s[GC_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void grad_combine_kernel(long total_pix, long npix, int C, CombineArgs a, View act, float slope, View out) {
+    const long n = total_pix * C;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long pg = e / C;
+        const int b = (int)(pg / npix);
+        const long p = pg - (long)b * npix;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < GC_MAX; ++j)
+            if (j < a.n) v += a.s[j] * Elem<T>::ld((const T*)a.t[j].p + voff(a.t[j], b, p, c));
+        if (act.p && !(Elem<T>::ld((const T*)act.p + voff(act, b, p, c)) > 0.f)) v *= slope;
+        Elem<T>::st((T*)out.p + voff(out, b, p, c), v);
+    }
+}
+// bf16, 8 channels (16 bytes) per thread
+__global__ __launch_bounds__(256) void grad_combine_vec_kernel(long total_pix, long npix, int C8, CombineArgs a, View act, float slope, View out) {
+    const long n = total_pix * C8;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C8) * 8;
+        const long pg = e / C8;
+        const int b = (int)(pg / npix);
+        const long p = pg - (long)b * npix;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < GC_MAX; ++j)
+            if (j < a.n) {
+                const uint4 q = *(const uint4*)((const bf16_t*)a.t[j].p + voff(a.t[j], b, p, c));
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] += a.s[j] * lo_f(w[i]);
+                    v[2 * i + 1] += a.s[j] * hi_f(w[i]);
+                }
+            }
+        if (act.p) {
+            const uint4 q = *(const uint4*)((const bf16_t*)act.p + voff(act, b, p, c));
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!(lo_f(w[i]) > 0.f)) v[2 * i] *= slope;
+                if (!(hi_f(w[i]) > 0.f)) v[2 * i + 1] *= slope;
+            }
+        }
+        *(uint4*)((bf16_t*)out.p + voff(out, b, p, c)) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(int B, int Hs, int Ws, int C, View src, View dst) {
+    const int H = 2 * Hs, W = 2 * Ws;
+    const long n = (long)B * H * W * C;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H), b = (int)(r / H);
+        Elem<T>::st((T*)dst.p + voff(dst, b, (long)h * W + w, c), Elem<T>::ld((const T*)src.p + voff(src, b, (long)(h >> 1) * Ws + (w >> 1), c)));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void downsum2x_kernel(int B, int Hs, int Ws, int C, View src, View dst) {
+    const int W = 2 * Ws;
+    const long n = (long)B * Hs * Ws * C;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int w = (int)(r % Ws);
+        r /= Ws;
+        const int h = (int)(r % Hs), b = (int)(r / Hs);
+        const long p = (long)(2 * h) * W + 2 * w;
+        const T* sp = (const T*)src.p;
+        const float v = Elem<T>::ld(sp + voff(src, b, p, c)) + Elem<T>::ld(sp + voff(src, b, p + 1, c)) +
+                        Elem<T>::ld(sp + voff(src, b, p + W, c)) + Elem<T>::ld(sp + voff(src, b, p + W + 1, c));
+        Elem<T>::st((T*)dst.p + voff(dst, b, (long)h * Ws + w, c), v);
+    }
+}
+
 static bool plain_view_ok(const sr_view& v, int C) {
     return v.p && v.C == C && v.c0 >= 0 && v.ld >= 1 && (v.cbs || v.c0 + v.C <= v.ld) && view_block_ok(v);
 }
@@ -687,8 +801,10 @@ extern "C" int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat*
 }
 
 extern "C" int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_view l2, sr_view l4, sr_view l8, const float* gates,
-                               sr_view da, sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, void* stream) {
+                               sr_view da, sr_view dx, sr_view dl2, sr_view dl4, sr_view dl8, float* dlogits, int accumulate,
+                               void* dlogits_bf16x32, void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && gates && dlogits && x.C > 0);
+    SR_REQUIRE(!dlogits_bf16x32 || (uintptr_t)dlogits_bf16x32 % 16 == 0);
     const int C = x.C;
     const sr_view* vs[9] = {&x, &l2, &l4, &l8, &da, &dx, &dl2, &dl4, &dl8};
     for (const sr_view* v : vs) SR_REQUIRE(plain_view_ok(*v, C));
@@ -698,7 +814,7 @@ extern "C" int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_vie
 #define SR_FB(T)                                                                                                                 \
     fbm_backward_kernel<T><<<grid, 256, 0, st>>>(total, npix, C, to_view(x, npix), to_view(l2, npix), to_view(l4, npix),      \
                                                  to_view(l8, npix), gates, to_view(da, npix), to_view(dx, npix),                \
-                                                 to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits)
+                                                 to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits, accumulate, (bf16_t*)dlogits_bf16x32)
     bool vec = dtype == SR_BF16 && C % 8 == 0 && C <= 256 && !g_wgrad_valu;  // (the hook keeps the scalar kernel: A/B test)
     for (const sr_view* v : vs) vec = vec && wm_view_ok(to_view(*v, npix));
     if (vec) {
@@ -708,7 +824,7 @@ extern "C" int sr_fbm_backward(int dtype, int B, int H, int W, sr_view x, sr_vie
 #define SR_FBV(PC_)                                                                                                             \
     fbm_backward_vec_kernel<PC_><<<gridv, 256, 0, st>>>(total, npix, C, to_view(x, npix), to_view(l2, npix), to_view(l4, npix), \
                                                         to_view(l8, npix), gates, to_view(da, npix), to_view(dx, npix),          \
-                                                        to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits)
+                                                        to_view(dl2, npix), to_view(dl4, npix), to_view(dl8, npix), dlogits, accumulate, (bf16_t*)dlogits_bf16x32)
         if (pc == 8) SR_FBV(8);
         else if (pc == 16) SR_FBV(16);
         else SR_FBV(32);
@@ -727,8 +843,16 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
     SR_REQUIRE(lp->gate_w[0] && lp->gate_w[1] && lp->gate_w[2]);
     SR_REQUIRE(!dpooled || dpooled_ld >= x.C);
     const int C = x.C;
-    const sr_view* vs[6] = {&x, &dx_direct, &a2, &a4, &a8, &dx_out};
+    const bool adj = a2.p != nullptr;  // the three adjoint low-pass terms: all or none
+    SR_REQUIRE((a4.p != nullptr) == adj && (a8.p != nullptr) == adj);
+    const sr_view* vs[3] = {&x, &dx_direct, &dx_out};
     for (const sr_view* v : vs) SR_REQUIRE(plain_view_ok(*v, C));
+    if (adj) {
+        const sr_view* va[3] = {&a2, &a4, &a8};
+        for (const sr_view* v : va) SR_REQUIRE(plain_view_ok(*v, C));
+    } else {
+        a2 = a4 = a8 = sr_view{};
+    }
     const long npix = (long)H * W, total = (long)B * npix;
     hipStream_t st = (hipStream_t)stream;
     if (dgate_w) {
@@ -750,8 +874,8 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
         }                                                                                                                        \
     } while (0)
     bool vec = dtype == SR_BF16 && C % 8 == 0 && C <= 256 && !g_wgrad_valu && (!dpooled || (dpooled_ld % 4 == 0 && (uintptr_t)dpooled % 16 == 0));
-    const sr_view* vv[5] = {&dx_direct, &a2, &a4, &a8, &dx_out};
-    for (const sr_view* v : vv) vec = vec && wm_view_ok(to_view(*v, npix));
+    const sr_view* vv[5] = {&dx_direct, &dx_out, &a2, &a4, &a8};
+    for (int i = 0; i < (adj ? 5 : 2); ++i) vec = vec && wm_view_ok(to_view(*vv[i], npix));
     if (vec) {
         const int pc = C <= 64 ? 8 : (C <= 128 ? 16 : 32);
         const int ppbv = 128;  // pixels per workgroup (the 27 x C gate weights are staged once for them); 1024 left half the CUs idle at the training sizes: 485 us against 208 us for the channel-per-lane kernel
@@ -772,5 +896,48 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
     } else if (dtype == SR_F32) SR_GB(float);
     else SR_GB(bf16_t);
 #undef SR_GB
+    return SR_OK;
+}
+
+extern "C" int sr_grad_combine(int dtype, int B, int H, int W, int C, int nterms, const sr_view* terms, const float* scales, sr_view act,
+                               float slope, sr_view out, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && nterms >= 1 && nterms <= GC_MAX && terms && scales);
+    SR_REQUIRE(plain_view_ok(out, C) && (!act.p || plain_view_ok(act, C)));
+    const long npix = (long)H * W, total = (long)B * npix;
+    CombineArgs a{};
+    a.n = nterms;
+    bool vec = dtype == SR_BF16 && C % 8 == 0 && wm_view_ok(to_view(out, npix)) && (!act.p || wm_view_ok(to_view(act, npix)));
+    for (int j = 0; j < nterms; ++j) {
+        SR_REQUIRE(plain_view_ok(terms[j], C));
+        a.t[j] = to_view(terms[j], npix);
+        a.s[j] = scales[j];
+        vec = vec && wm_view_ok(a.t[j]);
+    }
+    View av{};
+    if (act.p) av = to_view(act, npix);
+    hipStream_t st = (hipStream_t)stream;
+    const long work = vec ? total * (C / 8) : total * C;
+    const int grid = (int)((work + 255) / 256 < 65535 ? (work + 255) / 256 : 65535);
+    if (vec) grad_combine_vec_kernel<<<grid, 256, 0, st>>>(total, npix, C / 8, a, av, slope, to_view(out, npix));
+    else if (dtype == SR_F32) grad_combine_kernel<float><<<grid, 256, 0, st>>>(total, npix, C, a, av, slope, to_view(out, npix));
+    else grad_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(total, npix, C, a, av, slope, to_view(out, npix));
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_upsample2x(int dtype, int B, int Hs, int Ws, int C, sr_view src, sr_view dst, int adjoint, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && Hs > 0 && Ws > 0 && C > 0 && plain_view_ok(src, C) && plain_view_ok(dst, C));
+    hipStream_t st = (hipStream_t)stream;
+    const long lo = (long)Hs * Ws, hi = 4 * lo;
+    const long work = (long)B * (adjoint ? lo : hi) * C;
+    const int grid = (int)((work + 255) / 256 < 65535 ? (work + 255) / 256 : 65535);
+    if (!adjoint) {
+        if (dtype == SR_F32) upsample2x_kernel<float><<<grid, 256, 0, st>>>(B, Hs, Ws, C, to_view(src, lo), to_view(dst, hi));
+        else upsample2x_kernel<bf16_t><<<grid, 256, 0, st>>>(B, Hs, Ws, C, to_view(src, lo), to_view(dst, hi));
+    } else {
+        if (dtype == SR_F32) downsum2x_kernel<float><<<grid, 256, 0, st>>>(B, Hs, Ws, C, to_view(src, hi), to_view(dst, lo));
+        else downsum2x_kernel<bf16_t><<<grid, 256, 0, st>>>(B, Hs, Ws, C, to_view(src, hi), to_view(dst, lo));
+    }
+    SR_LAUNCH_CHECK();
     return SR_OK;
 }

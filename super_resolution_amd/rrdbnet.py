@@ -85,9 +85,10 @@ class RRDBNet(nn.Module):
 
     def _sr_invalidate(self):
         self._sr = None
+        self.__dict__['_sr_train_params'] = None
 
     def _apply(self, fn, *a, **k):
-        self._sr = None
+        self._sr_invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):

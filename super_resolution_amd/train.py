@@ -263,7 +263,7 @@ class _FDConvFn(torch.autograd.Function):
             dxd, dl2, dl4, dl8 = (torch.empty_like(xn) for _ in range(4))
             dz = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
             L.check(lib.sr_fbm_backward(code, B, H, W, L.view(xn), L.view(b2), L.view(b4), L.view(b8), gates.data_ptr(), L.view(da),
-                                        L.view(dxd), L.view(dl2), L.view(dl4), L.view(dl8), dz.data_ptr(), st), 'sr_fbm_backward')
+                                        L.view(dxd), L.view(dl2), L.view(dl4), L.view(dl8), dz.data_ptr(), 0, None, st), 'sr_fbm_backward')
             # 4. the band branches back through the (self-adjoint) low-pass: plane k of lowpass(dl_k)
             ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, cin), dtype=torch.uint8, device=dev)
             # (a view with a NULL pointer = band not wanted: each call synthesises one band only)
@@ -324,35 +324,420 @@ def conv_train(m, x):
     return _PlainConvFn.apply(x, m.weight, m.bias)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# the whole network as ONE autograd node: virtual concat, per-produced-tensor low-pass, hand-written backward schedule
+# ------------------------------------------------------------------------------------------------------------------
+class _Group:
+    """The tensors that feed one set of conv layers together, as ONE NHWC buffer: a dense block's x, x1..x4 are channel
+    slices of `x` (the torch.cat of basicsr's ResidualDenseBlock never exists: layer k reads the channel prefix, writes
+    its output slice), with the three low-pass planes and the pooled means of every slice beside it -- computed once per
+    PRODUCED tensor (192 channels per dense block, not 640) and shared by the layers that consume it.  Backward keeps one
+    accumulator per buffer (dx, dl2, dl4, dl8): every consumer adds its branch gradients in place, and the adjoint
+    low-pass runs once per slice on the sums."""
+
+    def __init__(self, B, H, W, Cc, dt, dev, bands, x=None):
+        self.B, self.H, self.W, self.C, self.dt, self.dev = B, H, W, Cc, dt, dev
+        self.x = x if x is not None else torch.empty(B, H, W, Cc, dtype=dt, device=dev)
+        self.has_bands = bands
+        if bands:
+            self.l2, self.l4, self.l8 = (torch.empty_like(self.x) for _ in range(3))
+            self.pooled = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+        self.dx = self.dl2 = self.dl4 = self.dl8 = None
+
+    def open_backward(self, covers_all):
+        """Called by every consumer in backward; True for the one that must WRITE the accumulators instead of adding to
+        them: the first consumer, provided it covers every channel and every accumulator (in RRDBNet: conv5 of a dense
+        block, or the only consumer).  Otherwise the accumulators start from zeros."""
+        if self.dx is not None:
+            return False
+        make = torch.empty_like if covers_all else torch.zeros_like
+        self.dx = make(self.x)
+        if self.has_bands:
+            self.dl2, self.dl4, self.dl8 = (make(self.x) for _ in range(3))
+        return covers_all
+
+
+class _Runner:
+    """Forward / backward of RRDBNet on libsr_amd for one call (holds the activations between the two passes)."""
+
+    def __init__(self, net, x, training):
+        self.net, self.training = net, training
+        self.lib, self.dev = L.lib(), x.device
+        self.io_dt = x.dtype
+        self.dt = net.compute_dtype if net.compute_dtype is not None else x.dtype
+        if self.dt not in (torch.float32, torch.bfloat16):
+            raise TypeError('RRDBNet (train): the training path computes in float32 or bfloat16 (got %s)' % self.dt)
+        self.code = L.dtype_code(self.dt)
+        self.st = L.stream_ptr(self.dev)
+        self.plans = {}
+        self.ws = None
+        self.bn_counters = []
+
+    # ---- small pieces ------------------------------------------------------------------------------------------
+    def plan(self, m, H, W):
+        return m._plan(H, W)
+
+    def workspace(self, nbytes):
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        return self.ws
+
+    def lowpass(self, plan, grp, c0, Cc, src=None, only=None, outs=None):
+        """Forward use: bands + pooled means of channels [c0, c0 + Cc) of grp.x.  Adjoint use (src / only / outs given):
+        plane `only` of the low-pass of `src` into outs[only]."""
+        lib, B = self.lib, grp.B
+        ws = self.workspace(lib.sr_fbm_workspace_bytes(plan, B, Cc))
+        if src is None:
+            L.check(lib.sr_fbm_lowpass(plan, self.code, B, L.view(grp.x, Cc, c0), 0, L.view(grp.l2, Cc, c0), L.view(grp.l4, Cc, c0),
+                                       L.view(grp.l8, Cc, c0), grp.pooled.data_ptr() + 4 * c0, grp.C, ws.data_ptr(), ws.numel(), self.st),
+                    'sr_fbm_lowpass')
+        else:
+            planes = [L.View(), L.View(), L.View()]
+            planes[only] = outs
+            L.check(lib.sr_fbm_lowpass(plan, self.code, B, src, 0, planes[0], planes[1], planes[2], None, 0, ws.data_ptr(), ws.numel(),
+                                       self.st), 'sr_fbm_lowpass (adjoint)')
+
+    def combine(self, B, H, W, Cc, terms, scales, act=None, slope=1.0, out=None):
+        """out = mask(act) * sum_j scales[j] * terms[j]; terms / act / out are sr_views; returns the output tensor."""
+        res = None
+        if out is None:
+            res = torch.empty(B, H, W, Cc, dtype=self.dt, device=self.dev)
+            out = L.view(res)
+        tv = (L.View * len(terms))(*terms)
+        sv = (C.c_float * len(terms))(*scales)
+        L.check(self.lib.sr_grad_combine(self.code, B, H, W, Cc, len(terms), tv, sv, act if act is not None else L.View(), float(slope),
+                                         out, self.st), 'sr_grad_combine')
+        return res
+
+    def resample(self, src, adjoint):
+        B, H, W, Cc = src.shape
+        Hs, Ws = (H // 2, W // 2) if adjoint else (H, W)
+        dst = torch.empty(B, Hs if adjoint else 2 * H, Ws if adjoint else 2 * W, Cc, dtype=src.dtype, device=src.device)
+        L.check(self.lib.sr_upsample2x(self.code, B, Hs, Ws, Cc, L.view(src), L.view(dst), int(adjoint), self.st), 'sr_upsample2x')
+        return dst
+
+    @staticmethod
+    def active(m):
+        return isinstance(m, FDConv) and m.fdconv_active
+
+    # ---- one conv layer ----------------------------------------------------------------------------------------
+    def layer_forward(self, m, grp, cin, out_view, lrelu=False, r1=None, s1=0.0, r2=None, s2=0.0):
+        """Layer `m` on the channel prefix [0, cin) of grp.x -> out_view (an sr_view of cout channels).  Returns the record
+        backward needs."""
+        if m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1) or m.groups != 1 or m.dilation != (1, 1):
+            raise NotImplementedError('libsr_amd implements 3x3 / stride 1 / padding 1 convolutions')
+        lib, dt, dev, st = self.lib, self.dt, self.dev, self.st
+        B, H, W = grp.B, grp.H, grp.W
+        cout = m.out_channels
+        if cin != m.in_channels:
+            raise RuntimeError('expected %d input channels, got %d' % (m.in_channels, cin))
+        split = dt == torch.bfloat16
+        ep = L.Epilogue()
+        ep.lrelu = int(lrelu)
+        if r1 is not None:
+            ep.r1, ep.s1 = r1, s1
+        if r2 is not None:
+            ep.r2, ep.s2 = r2, s2
+        cc = L.Concat()
+        cc.nseg = 1
+        cc.x[0] = L.view(grp.x, cin, 0)
+        rec = dict(m=m, grp=grp, cin=cin, active=self.active(m))
+        if not rec['active']:
+            n = 9 * cout * cin
+            wp = torch.empty(2 if split else 1, 1, 9, cout, cin, dtype=dt, device=dev)
+            L.check(lib.sr_pack_conv_weight(m.weight.detach().contiguous().data_ptr(), wp[0].data_ptr(), wp[1].data_ptr() if split else None,
+                                            self.code, cout, cin, st), 'sr_pack_conv_weight')
+            ep.bias = None if m.bias is None else m.bias.detach().data_ptr()
+            L.check(lib.sr_conv3x3(self.code, B, H, W, C.byref(cc), None, wp.data_ptr(), 0, n if split else 0, cout, C.byref(ep), out_view,
+                                   st), 'sr_conv3x3')
+            rec.update(w=wp)
+            return rec
+        if self.training and B < 2:
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                             % (torch.Size([B, m.KSM_Global.fc.out_channels, 1, 1]),))  # nn.BatchNorm2d's own error
+        lp, _keep = m.sr_layer_params(dt)
+        gates = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+        L.check(lib.sr_fbm_gates(self.code, B, H, W, C.byref(cc), C.byref(lp), gates.data_ptr(), st), 'sr_fbm_gates')
+        wdyn = torch.empty(2 if split else 1, B, 9, cout, cin, dtype=dt, device=dev)
+        mods = torch.empty(lib.sr_fdconv_weightgen_workspace_bytes(B, cin, cout), dtype=torch.uint8, device=dev)
+        bn = m.KSM_Global.bn
+        mom = 0.0
+        if self.training and bn.track_running_stats:
+            self.bn_counters.append(bn.num_batches_tracked)   # all counters of the network: one fused increment per forward
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+        L.check(lib.sr_fdconv_weightgen(self.code, B, grp.pooled.data_ptr(), grp.C, C.byref(lp), int(self.training), float(mom),
+                                        wdyn[0].data_ptr(), wdyn[1].data_ptr() if split else None, mods.data_ptr(), mods.numel(), st),
+                'sr_fdconv_weightgen')
+        cc.bands = 1
+        cc.l2[0], cc.l4[0], cc.l8[0] = L.view(grp.l2, cin, 0), L.view(grp.l4, cin, 0), L.view(grp.l8, cin, 0)
+        ep.bias = lp.bias
+        L.check(lib.sr_conv3x3(self.code, B, H, W, C.byref(cc), gates.data_ptr(), wdyn.data_ptr(), 9 * cout * cin,
+                               B * 9 * cout * cin if split else 0, cout, C.byref(ep), out_view, st), 'sr_conv3x3')
+        rec.update(gates=gates, w=wdyn, mods=mods, lp=lp, keep=_keep)
+        return rec
+
+    def layer_backward(self, rec, dyn, grads, need_dx=True):
+        """dyn: (B, H, W, cout) gradient wrt the layer's conv output (before its epilogue activation / residuals, which the
+        caller has already folded into dyn).  Adds the layer's input-side gradients to its group's accumulators and its
+        parameter gradients to `grads` ({parameter: tensor})."""
+        lib, st, dev = self.lib, self.st, self.dev
+        m, grp, cin = rec['m'], rec['grp'], rec['cin']
+        B, H, W = grp.B, grp.H, grp.W
+        cout = m.out_channels
+        first = grp.open_backward(cin == grp.C and (rec['active'] or not grp.has_bands))
+        xv = L.view(grp.x, cin, 0)
+        cc = L.Concat()
+        cc.nseg = 1
+        cc.x[0] = xv
+        params = dict(m.named_parameters(recurse=False)) if not rec['active'] else _named_params(m)[2]
+        if not rec['active']:
+            wp = rec['w']
+            dw = torch.empty(9, cout, cin, dtype=torch.float32, device=dev)
+            db = torch.empty(cout, dtype=torch.float32, device=dev) if m.bias is not None else None
+            L.check(lib.sr_conv3x3_wgrad(self.code, B, H, W, C.byref(cc), None, L.view(dyn), cout, 0, dw.data_ptr(), L.ptr(db), st),
+                    'sr_conv3x3_wgrad')
+            grads[params['weight']] = dw.permute(1, 2, 0).reshape(cout, cin, 3, 3)
+            if db is not None:
+                grads[params['bias']] = db
+            if need_dx:
+                wt = _transposed(wp, 1, cout, cin)
+                da = _conv(dyn, _concat1(dyn), None, wt, 0, cin, None, 9 * cin * cout if wt.shape[0] == 2 else 0)
+                dxv = L.view(grp.dx, cin, 0)
+                self.combine(B, H, W, cin, [L.view(da)] + ([] if first else [dxv]), [1.0] + ([] if first else [1.0]), out=dxv)
+            return
+        lp, gates, wdyn = rec['lp'], rec['gates'], rec['w']
+        cc.bands = 1
+        cc.l2[0], cc.l4[0], cc.l8[0] = L.view(grp.l2, cin, 0), L.view(grp.l4, cin, 0), L.view(grp.l8, cin, 0)
+        # 1. weight / bias gradients of the convolution
+        dw = torch.empty(B, 9, cout, cin, dtype=torch.float32, device=dev)
+        db = torch.empty(cout, dtype=torch.float32, device=dev) if m.bias is not None else None
+        L.check(lib.sr_conv3x3_wgrad(self.code, B, H, W, C.byref(cc), gates.data_ptr(), L.view(dyn), cout, 1, dw.data_ptr(), L.ptr(db), st),
+                'sr_conv3x3_wgrad')
+        if db is not None:
+            grads[params['bias']] = db
+        # 2. gradient wrt the modulated operand: convolution of dy with the transposed, mirrored weights
+        wt = _transposed(wdyn, B, cout, cin)
+        da = _conv(dyn, _concat1(dyn), None, wt, 9 * cin * cout, cin, None, B * 9 * cin * cout if wt.shape[0] == 2 else 0)
+        # 3. band mix: the four linear branches are ADDED to the group's accumulators (first consumer: written)
+        dz = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+        mfma_gates = self.dt == torch.bfloat16 and cin % 32 == 0
+        # gate-conv weight gradients on the matrix cores: the weight-gradient kernel with the logit gradients (three channels
+        # in a 32-wide bf16 pixel, written by the same kernel) in the place of dy
+        dzp = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device=dev) if mfma_gates else None
+        dxv = L.view(grp.dx, cin, 0)
+        L.check(lib.sr_fbm_backward(self.code, B, H, W, xv, cc.l2[0], cc.l4[0], cc.l8[0], gates.data_ptr(), L.view(da), dxv,
+                                    L.view(grp.dl2, cin, 0), L.view(grp.dl4, cin, 0), L.view(grp.dl8, cin, 0), dz.data_ptr(),
+                                    0 if first else 1, L.ptr(dzp), st), 'sr_fbm_backward')
+        # 4. the weight path: dW_b -> parameters and pooled means
+        wgrads, dpooled = weight_path_backward(m, lp, grp.pooled, grp.C, rec['mods'], dw, self.training)
+        for name, gten in wgrads.items():
+            grads[params[name]] = gten
+        # 5. gate convs: weight gradients, and their input gradient + the pooled-mean term added to the direct branch
+        if mfma_gates:
+            dw32 = torch.empty(9, 32, cin, dtype=torch.float32, device=dev)
+            db32 = torch.empty(32, dtype=torch.float32, device=dev)
+            cx = L.Concat()
+            cx.nseg = 1
+            cx.x[0] = xv
+            L.check(lib.sr_conv3x3_wgrad(self.code, B, H, W, C.byref(cx), None, L.view(dzp), 32, 0, dw32.data_ptr(), db32.data_ptr(), st),
+                    'sr_conv3x3_wgrad (gate convs)')
+            # (9, cin) slices of dw32 viewed as (1, cin, 3, 3): no copy (the optimizer's flatten reads them as they lie)
+            gate_w = [dw32[:, k, :].t().unsqueeze(0).view(1, cin, 3, 3) for k in range(3)]
+            gate_b = [db32[k:k + 1] for k in range(3)]
+            gw_ptr = gb_ptr = None
+        else:
+            dgw = torch.empty(3, cin, 9, dtype=torch.float32, device=dev)
+            dgb = torch.empty(3, dtype=torch.float32, device=dev)
+            gw_ptr, gb_ptr = dgw.data_ptr(), dgb.data_ptr()
+            gate_w = [dgw[k].reshape(1, cin, 3, 3) for k in range(3)]
+            gate_b = [dgb[k:k + 1] for k in range(3)]
+        nv = L.View()
+        L.check(lib.sr_fbm_gates_backward(self.code, B, H, W, xv, dz.data_ptr(), C.byref(lp), dxv, nv, nv, nv, dpooled.data_ptr(), cin, dxv,
+                                          gw_ptr, gb_ptr, st), 'sr_fbm_gates_backward')
+        for k in range(3):
+            grads[params['FBM.freq_weight_conv_list.%d.weight' % k]] = gate_w[k]
+            grads[params['FBM.freq_weight_conv_list.%d.bias' % k]] = gate_b[k]
+
+    def slice_grad(self, grp, plan, c0, Cc, act=None, slope=1.0, extras=()):
+        """Gradient wrt channels [c0, c0 + Cc) of grp.x once all their consumers have run: direct branch + adjoint low-pass
+        of the three band accumulators (+ residual-path terms `extras` = [(sr_view, scale)]), times the LeakyReLU mask of
+        the layer that produced the slice (act = its output) -- i.e. the dy of that producing layer."""
+        B, H, W = grp.B, grp.H, grp.W
+        terms, scales, held = [L.view(grp.dx, Cc, c0)], [1.0], []
+        if grp.has_bands:
+            for k, acc in enumerate((grp.dl2, grp.dl4, grp.dl8)):
+                out = torch.empty(B, H, W, Cc, dtype=self.dt, device=self.dev)
+                self.lowpass(plan, grp, c0, Cc, src=L.view(acc, Cc, c0), only=k, outs=L.view(out))
+                terms.append(L.view(out))
+                scales.append(1.0)
+                held.append(out)   # alive until the combine below has been enqueued
+        for v, sc in extras:
+            terms.append(v)
+            scales.append(sc)
+        return self.combine(B, H, W, Cc, terms, scales, act=act, slope=slope)
+
+    # ---- the network --------------------------------------------------------------------------------------------
+    def forward(self, x):
+        net, lib, dt, dev, st = self.net, self.lib, self.dt, self.dev, self.st
+        r = {4: 1, 2: 2, 1: 4}[net.scale]
+        B, Cin0, Hin, Win = x.shape
+        if Cin0 != net.num_in_ch:
+            raise RuntimeError('expected %d input channels, got %d' % (net.num_in_ch, Cin0))
+        if Hin % r or Win % r:
+            raise RuntimeError('input size must be divisible by %d for scale %d' % (r, net.scale))
+        H, W = Hin // r, Win // r
+        nf, gc, nb = net.num_feat, net.num_grow_ch, net.num_block
+        act = self.active
+        self.r, self.B, self.H, self.W = r, B, H, W
+        # network input, NHWC (pixel_unshuffle of scale 2 / 1 folded into the pack)
+        g_in = _Group(B, H, W, Cin0 * r * r, dt, dev, False)
+        L.check(lib.sr_pack_nchw(x.contiguous().data_ptr(), L.dtype_code(x.dtype), g_in.x.data_ptr(), self.code, B, Cin0, Hin, Win, r, st),
+                'sr_pack_nchw')
+        rdbs = [rdb for blk in net.body for rdb in (blk.rdb1, blk.rdb2, blk.rdb3)]
+        ctot = nf + 4 * gc
+        groups = []
+        for rdb in rdbs:
+            convs = (rdb.conv1, rdb.conv2, rdb.conv3, rdb.conv4, rdb.conv5)
+            groups.append(_Group(B, H, W, ctot, dt, dev, any(act(m) for m in convs)))
+        g_body = _Group(B, H, W, nf, dt, dev, act(net.conv_body))
+        first_out = groups[0] if groups else g_body
+        self.rec_first = self.layer_forward(net.conv_first, g_in, Cin0 * r * r, L.view(first_out.x, nf, 0))
+        self.g_in, self.groups, self.g_body = g_in, groups, g_body
+        self.recs = []
+        for n, rdb in enumerate(rdbs):
+            grp = groups[n]
+            nxt = groups[n + 1] if n + 1 < len(groups) else g_body
+            convs = (rdb.conv1, rdb.conv2, rdb.conv3, rdb.conv4, rdb.conv5)
+            plan = self.plan(next(m for m in convs if act(m)), H, W) if grp.has_bands else None
+            if grp.has_bands:
+                self.lowpass(plan, grp, 0, nf)
+            recs = []
+            for k, m in enumerate(convs):
+                cin = nf + k * gc
+                if k < 4:
+                    recs.append(self.layer_forward(m, grp, cin, L.view(grp.x, gc, cin), lrelu=True))
+                    if grp.has_bands:
+                        self.lowpass(plan, grp, cin, gc)
+                else:  # x5 * 0.2 + x ; the last dense block of an RRDB also takes the block's residual: (.) * 0.2 + block input
+                    last = n % 3 == 2
+                    recs.append(self.layer_forward(m, grp, cin, L.view(nxt.x, nf, 0), r1=L.view(grp.x, nf, 0), s1=0.2,
+                                                   r2=L.view(groups[n - 2].x, nf, 0) if last else None, s2=0.2))
+            self.recs.append(recs)
+        # conv_body + trunk residual
+        if g_body.has_bands:
+            self.lowpass(self.plan(net.conv_body, H, W), g_body, 0, nf)
+        f2 = torch.empty(B, H, W, nf, dtype=dt, device=dev)
+        self.rec_body = self.layer_forward(net.conv_body, g_body, nf, L.view(f2), r1=L.view(first_out.x, nf, 0), s1=1.0)
+        # upsampling head
+        g_u1 = _Group(B, 2 * H, 2 * W, nf, dt, dev, act(net.conv_up1), x=self.resample(f2, False))
+        if g_u1.has_bands:
+            self.lowpass(self.plan(net.conv_up1, 2 * H, 2 * W), g_u1, 0, nf)
+        v1 = torch.empty(B, 2 * H, 2 * W, nf, dtype=dt, device=dev)
+        self.rec_up1 = self.layer_forward(net.conv_up1, g_u1, nf, L.view(v1), lrelu=True)
+        g_u2 = _Group(B, 4 * H, 4 * W, nf, dt, dev, act(net.conv_up2), x=self.resample(v1, False))
+        if g_u2.has_bands:
+            self.lowpass(self.plan(net.conv_up2, 4 * H, 4 * W), g_u2, 0, nf)
+        g_hr = _Group(B, 4 * H, 4 * W, nf, dt, dev, act(net.conv_hr))
+        self.rec_up2 = self.layer_forward(net.conv_up2, g_u2, nf, L.view(g_hr.x), lrelu=True)
+        if g_hr.has_bands:
+            self.lowpass(self.plan(net.conv_hr, 4 * H, 4 * W), g_hr, 0, nf)
+        g_last = _Group(B, 4 * H, 4 * W, nf, dt, dev, act(net.conv_last))
+        self.rec_hr = self.layer_forward(net.conv_hr, g_hr, nf, L.view(g_last.x), lrelu=True)
+        if g_last.has_bands:
+            self.lowpass(self.plan(net.conv_last, 4 * H, 4 * W), g_last, 0, nf)
+        pred = torch.empty(B, 4 * H, 4 * W, net.num_out_ch, dtype=dt, device=dev)
+        self.rec_last = self.layer_forward(net.conv_last, g_last, nf, L.view(pred))
+        self.v1, self.g_u1, self.g_u2, self.g_hr, self.g_last = v1, g_u1, g_u2, g_hr, g_last
+        self.ws = None
+        if self.bn_counters:
+            torch._foreach_add_(self.bn_counters, 1)
+            self.bn_counters = []
+        return _unpack(pred).to(self.io_dt)
+
+    def backward(self, dpred, need_dx):
+        net = self.net
+        B, H, W = self.B, self.H, self.W
+        nf, gc = net.num_feat, net.num_grow_ch
+        grads = {}
+        pl = lambda m, h, w: self.plan(m, h, w) if self.active(m) else None
+        dyn = _pack(dpred.to(self.dt))
+        # conv_last <- conv_hr <- conv_up2 <- conv_up1 (each tensor has ONE consumer here)
+        self.layer_backward(self.rec_last, dyn, grads)
+        dy = self.slice_grad(self.g_last, pl(net.conv_last, 4 * H, 4 * W), 0, nf, act=L.view(self.g_last.x), slope=0.2)
+        self.layer_backward(self.rec_hr, dy, grads)
+        dy = self.slice_grad(self.g_hr, pl(net.conv_hr, 4 * H, 4 * W), 0, nf, act=L.view(self.g_hr.x), slope=0.2)
+        self.layer_backward(self.rec_up2, dy, grads)
+        d_u2 = self.slice_grad(self.g_u2, pl(net.conv_up2, 4 * H, 4 * W), 0, nf)
+        d_v1 = self.resample(d_u2, True)
+        dy = self.combine(B, 2 * H, 2 * W, nf, [L.view(d_v1)], [1.0], act=L.view(self.v1), slope=0.2)
+        self.layer_backward(self.rec_up1, dy, grads)
+        d_u1 = self.slice_grad(self.g_u1, pl(net.conv_up1, 2 * H, 2 * W), 0, nf)
+        d_f2 = self.resample(d_u1, True)          # gradient wrt f2 = conv_body(body) + feat
+        self.layer_backward(self.rec_body, d_f2, grads)
+        dout = self.slice_grad(self.g_body, pl(net.conv_body, H, W), 0, nf)   # gradient wrt the trunk's output
+        # the dense blocks, last to first
+        for n in range(len(self.groups) - 1, -1, -1):
+            grp, recs = self.groups[n], self.recs[n]
+            j = n % 3
+            if j == 2:
+                dblk = dout                         # gradient wrt the RRDB's output: out = rdb3 * 0.2 + block input
+            res_scale = 0.2 if j == 2 else 1.0      # what reaches this dense block's output from `dout`
+            plan = next((self.plan(r_['m'], H, W) for r_ in recs if r_['active']), None)
+            dy5 = self.combine(B, H, W, nf, [L.view(dout)], [0.2 * res_scale])   # x5 enters as x5 * 0.2
+            self.layer_backward(recs[4], dy5, grads)
+            for k in (3, 2, 1, 0):
+                c0 = nf + k * gc
+                dy = self.slice_grad(grp, plan, c0, gc, act=L.view(grp.x, gc, c0), slope=0.2)
+                self.layer_backward(recs[k], dy, grads)
+            extras = [(L.view(dout), res_scale)]    # the dense block's own residual (+ x)
+            if j == 0:
+                extras.append((L.view(dblk), 1.0))  # the RRDB's residual (+ block input)
+            dout = self.slice_grad(grp, plan, 0, nf, extras=extras)
+        # conv_first: the trunk input also feeds the long residual feat + conv_body(...)
+        dfeat = self.combine(B, H, W, nf, [L.view(dout), L.view(d_f2)], [1.0, 1.0])
+        self.layer_backward(self.rec_first, dfeat, grads, need_dx=need_dx)
+        dx = None
+        if need_dx:
+            if self.r != 1:
+                raise NotImplementedError('gradient wrt the input of a scale-%d network (pixel_unshuffle) is not implemented' % net.scale)
+            dx = _unpack(self.g_in.dx).to(self.io_dt)
+        return dx, grads
+
+
+class _NetFn(torch.autograd.Function):
+    """RRDBNet.forward as one autograd node; arguments after the module are its parameters (so that autograd routes their
+    gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, net, training, *params):
+        with torch.cuda.device(x.device):
+            run = _Runner(net, x, training)
+            y = run.forward(x)
+        ctx.run, ctx.params = run, params
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        run = ctx.run
+        if run is None:
+            raise RuntimeError('RRDBNet (train): backward through the same forward twice is not supported')
+        with torch.cuda.device(dy.device):
+            dx, grads = run.backward(dy, ctx.need_dx)
+        ctx.run = None  # free the activations
+        return (dx, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
 def rrdbnet_train_forward(net, x):
-    """RRDBNet.forward (basicsr rrdbnet_arch.py; call site train/train_realESRGAN_fdconv_1.py:114) with an autograd graph."""
+    """RRDBNet.forward (basicsr rrdbnet_arch.py; call site train/train_realESRGAN_fdconv_1.py:114) with an autograd graph:
+    ONE node for the whole network.  No torch operator runs between the layers: the dense-block concat is a channel-sliced
+    buffer, LeakyReLU / residual scaling live in the conv epilogues (forward) and in sr_grad_combine (backward), nearest 2x
+    and its adjoint are sr_upsample2x, low-pass planes and gates exist once per produced tensor."""
     _check_input(x, 'RRDBNet (train)')
-    io_dt = x.dtype
-    if net.compute_dtype is not None and net.compute_dtype != io_dt:  # e.g. float32 data, bf16 compute (mixed precision)
-        x = x.to(net.compute_dtype)
-        _check_input(x, 'RRDBNet (train)')
-    lrelu = lambda t: F.leaky_relu(t, 0.2)
-    if net.scale == 2:
-        x = F.pixel_unshuffle(x, 2)
-    elif net.scale == 1:
-        x = F.pixel_unshuffle(x, 4)
-    feat = conv_train(net.conv_first, x)
-    body = feat
-    for blk in net.body:
-        blk_in = body
-        for rdb in (blk.rdb1, blk.rdb2, blk.rdb3):
-            x0 = body
-            x1 = lrelu(conv_train(rdb.conv1, x0))
-            x2 = lrelu(conv_train(rdb.conv2, torch.cat((x0, x1), 1)))
-            x3 = lrelu(conv_train(rdb.conv3, torch.cat((x0, x1, x2), 1)))
-            x4 = lrelu(conv_train(rdb.conv4, torch.cat((x0, x1, x2, x3), 1)))
-            x5 = conv_train(rdb.conv5, torch.cat((x0, x1, x2, x3, x4), 1))
-            body = x5 * 0.2 + x0
-        body = body * 0.2 + blk_in
-    feat = feat + conv_train(net.conv_body, body)
-    feat = lrelu(conv_train(net.conv_up1, F.interpolate(feat, scale_factor=2, mode='nearest')))
-    feat = lrelu(conv_train(net.conv_up2, F.interpolate(feat, scale_factor=2, mode='nearest')))
-    return conv_train(net.conv_last, lrelu(conv_train(net.conv_hr, feat))).to(io_dt)
+    cache = net.__dict__.setdefault('_sr_train_params', None)
+    params = cache if cache is not None else list(net.parameters())
+    net.__dict__['_sr_train_params'] = params
+    return _NetFn.apply(x, net, net.training, *params)
 
 
 # ------------------------------------------------------------------------------------------------------------------

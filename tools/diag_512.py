@@ -17,9 +17,10 @@ from super_resolution_amd import _lib
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 do64 = len(sys.argv) > 2 and sys.argv[2] == '64'
-torch.manual_seed(3)
+SEED = int(os.environ.get('DIAG_SEED', '3'))
+torch.manual_seed(SEED)
 net = sra.replace_conv_with_fdconv(sra.RRDBNet(1, 1, 4, 64, 23, 32))
-g = torch.Generator().manual_seed(4)
+g = torch.Generator().manual_seed(SEED + 1)
 with torch.no_grad():
     for name, p in net.named_parameters():
         if any(s in name for s in ('KSM_Local.conv.weight', 'freq_weight_conv_list')) and p.dim() > 1:
@@ -40,6 +41,10 @@ with torch.no_grad():
     _lib.lib().sr_debug_force_fft_lowpass(1)
     yb_fft = net(x.cuda().to(torch.bfloat16)).float().cpu()
     _lib.lib().sr_debug_force_fft_lowpass(-1)
+    _lib.lib().sr_debug_force_generic_fft(1)
+    y32_gen = net(x.cuda()).cpu()
+    _lib.lib().sr_debug_force_generic_fft(0)
+    print('gpu32 (pow2 FFT) vs gpu32 (any-size FFT): max %.3e' % float((y32 - y32_gen).abs().max()), flush=True)
     t0 = time.time()
     ref32 = rrdbnet_forward(sd, x)
     print('oracle fp32 %.1f s' % (time.time() - t0), flush=True)
@@ -49,9 +54,14 @@ print('gpu32 vs ref32: max %.3e   psnr %.1f' % (float((y32 - ref32).abs().max())
 print('bf16 (mfma lowpass) vs gpu32: psnr %.1f   vs ref32 %.1f' % (psnr(yb, y32, span), psnr(yb, ref32, span)))
 print('bf16 (fft  lowpass) vs gpu32: psnr %.1f   vs ref32 %.1f' % (psnr(yb_fft, y32, span), psnr(yb_fft, ref32, span)), flush=True)
 if do64:
+    import threading
+    stop = threading.Event()
+    threading.Thread(target=lambda: [print('.', end='', flush=True) for _ in iter(lambda: stop.wait(30.0), True)], daemon=True).start()
     with torch.no_grad():
         t0 = time.time()
         ref64 = rrdbnet_forward(sd, x.double(), dtype=torch.float64)
-        print('oracle fp64 %.1f s' % (time.time() - t0))
+    stop.set()
+    print('oracle fp64 %.1f s' % (time.time() - t0))
     print('ref32 vs ref64: max %.3e psnr %.1f' % (float((ref32.double() - ref64).abs().max()), psnr(ref32, ref64, span)))
     print('gpu32 vs ref64: max %.3e psnr %.1f' % (float((y32.double() - ref64).abs().max()), psnr(y32, ref64, span)))
+    print('gpu32 (any-size FFT) vs ref64: max %.3e' % float((y32_gen.double() - ref64).abs().max()))
