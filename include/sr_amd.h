@@ -284,7 +284,14 @@ int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, const float
  * residual paths (x5 * 0.2 + x, out * 0.2 + x of basicsr's RDB / RRDB) -- with the backward of the LeakyReLU(0.2) that
  * produced the tensor folded in (autograd's AddBackward / LeakyReluBackward nodes in the reference). */
 int sr_grad_combine(int dtype, int B, int H, int W, int C, int nterms, const sr_view* terms, const float* scales, sr_view act,
-                    float slope, sr_view out, void* stream);
+                    float slope, const float* bc, int bc_ld, float bc_scale, sr_view out, void* stream);
+/* bc (may be NULL): float (B, bc_ld) values added as bc_scale * bc[b][c] to every pixel before the mask: the summed
+ * pooled-mean gradients of a tensor's consumers (backward of F.adaptive_avg_pool2d at FDConv.py:643, bc_scale = 1 / (H W)).
+ *
+ * The three transposed gate convs of a layer (backward of FDConv.py:460 with respect to its input) as one 32 -> cin
+ * convolution for sr_conv3x3 over the (B,H,W,32) bf16 logit gradients of sr_fbm_backward:
+ * hi / lo [9][cin][32] bf16 = mirrored taps of gate_w[k] in input channel k < 3, zeros elsewhere (w = hi + lo). */
+int sr_pack_gate_weight_transposed(const sr_layer_params* lp, void* hi, void* lo, void* stream);
 /* adjoint == 0: dst (B,2Hs,2Ws,C) = F.interpolate(src (B,Hs,Ws,C), scale_factor=2, mode='nearest') (RRDBNet.forward);
  * adjoint != 0: dst (B,Hs,Ws,C) = 2 x 2 sums of src (B,2Hs,2Ws,C) (its backward). */
 int sr_upsample2x(int dtype, int B, int Hs, int Ws, int C, sr_view src, sr_view dst, int adjoint, void* stream);
@@ -299,7 +306,8 @@ int sr_upsample2x(int dtype, int B, int Hs, int Ws, int C, sr_view src, sr_view 
  *   grads  one float32 output per parameter, each OVERWRITTEN, shapes of the state_dict entries:
  *          dft_weight (3 cout, 3 cin / 2 + 1, 2) -- by linearity  d dft[r][c] = alpha w_c / (9 cout cin) rfft2(S_G(r,c))[r][c]
  *          with S_g = sum_b ka[b][g] dA[b] (adjoint of the C2R transform, w_c = 1 on the self-conjugate columns, else 2)
- *   dpooled (B, dpooled_ld) float, OVERWRITTEN: gradient with respect to the pooled means (both KSM branches).
+ *   dpooled (B, dpooled_ld) float: gradient with respect to the pooled means (both KSM branches); OVERWRITTEN, or with
+ *          accumulate != 0 ADDED to (a tensor of a dense block feeds several layers).
  * Sums over the batch inside wp_elem / wp_ln are float atomics (last bits vary from run to run). */
 typedef struct {
     float* dft_weight;
@@ -313,8 +321,8 @@ typedef struct {
 size_t sr_fdconv_weightgen_backward_workspace_bytes(int B, int cin, int cout);
 int sr_fdconv_weightgen_backward(int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, int train, const float* mods,
                                  const float* dft_weight, const uint8_t* gmap, float alpha, const float* dw,
-                                 const sr_weight_path_grads* grads, float* dpooled, int dpooled_ld, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+                                 const sr_weight_path_grads* grads, float* dpooled, int dpooled_ld, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- whole network (RRDBNet.forward) ------------------------------------------------------- */
 typedef struct sr_rrdbnet sr_rrdbnet;

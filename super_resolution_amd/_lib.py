@@ -83,14 +83,15 @@ _SIGS = {
     'sr_fdconv_weightgen_backward_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_fdconv_weightgen_backward': (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(LayerParams), C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_float, C.c_void_p, C.POINTER(WeightPathGrads), C.c_void_p, C.c_int,
-                                               C.c_void_p, C.c_size_t, C.c_void_p]),
+                                               C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_conv_weight_transpose': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_conv3x3_wgrad': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Concat), C.c_void_p, View, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_fbm_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, View, View, View, C.c_void_p, View, View, View, View,
                                   View, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'sr_grad_combine': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(View), C.POINTER(C.c_float), View,
-                                  C.c_float, View, C.c_void_p]),
+                                  C.c_float, C.c_void_p, C.c_int, C.c_float, View, C.c_void_p]),
+    'sr_pack_gate_weight_transposed': (C.c_int, [C.POINTER(LayerParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_upsample2x': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, View, View, C.c_int, C.c_void_p]),
     'sr_fbm_gates_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, View, C.c_void_p, C.POINTER(LayerParams), View, View,
                                         View, View, C.c_void_p, C.c_int, View, C.c_void_p, C.c_void_p, C.c_void_p]),

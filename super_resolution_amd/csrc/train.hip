@@ -656,7 +656,8 @@ struct CombineArgs {
     float s[GC_MAX];
 };
 template <typename T>
-__global__ __launch_bounds__(256) void grad_combine_kernel(long total_pix, long npix, int C, CombineArgs a, View act, float slope, View out) {
+__global__ __launch_bounds__(256) void grad_combine_kernel(long total_pix, long npix, int C, CombineArgs a, View act, float slope, View out,
+                                                           const float* __restrict__ bc, int bc_ld, float bc_scale) {
     const long n = total_pix * C;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const int c = (int)(e % C);
@@ -667,12 +668,14 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(long total_pix, long 
 #pragma unroll
         for (int j = 0; j < GC_MAX; ++j)
             if (j < a.n) v += a.s[j] * Elem<T>::ld((const T*)a.t[j].p + voff(a.t[j], b, p, c));
+        if (bc) v += bc_scale * bc[(long)b * bc_ld + c];
         if (act.p && !(Elem<T>::ld((const T*)act.p + voff(act, b, p, c)) > 0.f)) v *= slope;
         Elem<T>::st((T*)out.p + voff(out, b, p, c), v);
     }
 }
 // bf16, 8 channels (16 bytes) per thread
-__global__ __launch_bounds__(256) void grad_combine_vec_kernel(long total_pix, long npix, int C8, CombineArgs a, View act, float slope, View out) {
+__global__ __launch_bounds__(256) void grad_combine_vec_kernel(long total_pix, long npix, int C8, CombineArgs a, View act, float slope, View out,
+                                                               const float* __restrict__ bc, int bc_ld, float bc_scale) {
     const long n = total_pix * C8;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const int c = (int)(e % C8) * 8;
@@ -691,6 +694,10 @@ __global__ __launch_bounds__(256) void grad_combine_vec_kernel(long total_pix, l
                     v[2 * i + 1] += a.s[j] * hi_f(w[i]);
                 }
             }
+        if (bc) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += bc_scale * bc[(long)b * bc_ld + c + i];
+        }
         if (act.p) {
             const uint4 q = *(const uint4*)((const bf16_t*)act.p + voff(act, b, p, c));
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -701,6 +708,22 @@ __global__ __launch_bounds__(256) void grad_combine_vec_kernel(long total_pix, l
             }
         }
         *(uint4*)((bf16_t*)out.p + voff(out, b, p, c)) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
+// transposed gate convs as ONE 32 -> C convolution for sr_conv3x3: W'[t][c][k] = gate_w_k[c][8 - t] for k < 3, zero for the
+// other 29 input channels (the logit gradients travel as 32-channel bf16 pixels), split into hi + lo bf16 parts
+__global__ __launch_bounds__(256) void pack_gate_wt_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
+                                                           const float* __restrict__ g2, int C, bf16_t* __restrict__ hi,
+                                                           bf16_t* __restrict__ lo) {
+    const int n = 9 * C * 32;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int k = e & 31, c = (e >> 5) % C, t = e / (32 * C);
+        float v = 0.f;
+        if (k < 3) v = (k == 0 ? g0 : (k == 1 ? g1 : g2))[c * 9 + (8 - t)];
+        const bf16_t h = f32_to_bf16(v);
+        hi[e] = h;
+        lo[e] = f32_to_bf16(v - bf16_to_f32(h));
     }
 }
 
@@ -900,8 +923,9 @@ extern "C" int sr_fbm_gates_backward(int dtype, int B, int H, int W, sr_view x, 
 }
 
 extern "C" int sr_grad_combine(int dtype, int B, int H, int W, int C, int nterms, const sr_view* terms, const float* scales, sr_view act,
-                               float slope, sr_view out, void* stream) {
+                               float slope, const float* bc, int bc_ld, float bc_scale, sr_view out, void* stream) {
     SR_REQUIRE(dtype_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && nterms >= 1 && nterms <= GC_MAX && terms && scales);
+    SR_REQUIRE(!bc || bc_ld >= C);
     SR_REQUIRE(plain_view_ok(out, C) && (!act.p || plain_view_ok(act, C)));
     const long npix = (long)H * W, total = (long)B * npix;
     CombineArgs a{};
@@ -918,9 +942,9 @@ extern "C" int sr_grad_combine(int dtype, int B, int H, int W, int C, int nterms
     hipStream_t st = (hipStream_t)stream;
     const long work = vec ? total * (C / 8) : total * C;
     const int grid = (int)((work + 255) / 256 < 65535 ? (work + 255) / 256 : 65535);
-    if (vec) grad_combine_vec_kernel<<<grid, 256, 0, st>>>(total, npix, C / 8, a, av, slope, to_view(out, npix));
-    else if (dtype == SR_F32) grad_combine_kernel<float><<<grid, 256, 0, st>>>(total, npix, C, a, av, slope, to_view(out, npix));
-    else grad_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(total, npix, C, a, av, slope, to_view(out, npix));
+    if (vec) grad_combine_vec_kernel<<<grid, 256, 0, st>>>(total, npix, C / 8, a, av, slope, to_view(out, npix), bc, bc_ld, bc_scale);
+    else if (dtype == SR_F32) grad_combine_kernel<float><<<grid, 256, 0, st>>>(total, npix, C, a, av, slope, to_view(out, npix), bc, bc_ld, bc_scale);
+    else grad_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(total, npix, C, a, av, slope, to_view(out, npix), bc, bc_ld, bc_scale);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -938,6 +962,15 @@ extern "C" int sr_upsample2x(int dtype, int B, int Hs, int Ws, int C, sr_view sr
         if (dtype == SR_F32) downsum2x_kernel<float><<<grid, 256, 0, st>>>(B, Hs, Ws, C, to_view(src, hi), to_view(dst, lo));
         else downsum2x_kernel<bf16_t><<<grid, 256, 0, st>>>(B, Hs, Ws, C, to_view(src, hi), to_view(dst, lo));
     }
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_pack_gate_weight_transposed(const sr_layer_params* lp, void* hi, void* lo, void* stream) {
+    SR_REQUIRE(lp && hi && lo && lp->cin > 0 && lp->gate_w[0] && lp->gate_w[1] && lp->gate_w[2]);
+    const int n = 9 * lp->cin * 32;
+    pack_gate_wt_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(lp->gate_w[0], lp->gate_w[1], lp->gate_w[2], lp->cin, (bf16_t*)hi,
+                                                                       (bf16_t*)lo);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

@@ -8,14 +8,14 @@
 // Given dW [B][9][cout][cin] this file returns the gradients of every parameter on that path and of the pooled means.
 //
 // Kernels (one C entry point launches all of them):
-//   wp_elem      per element: dA = dW M R (M = sa ca fa), dlogit = dW M A R (1 - R/2), and the reductions
-//                dsa, dca, dfa (sums of dW R A times the two other factors) and dka_g = <dA, Basis_g>
-//   wp_groupsum  S_g = sum_b ka[b][g] dA[b]   in the (3 cout, 3 cin) spatial layout of the spectrum's inverse transform
+//   wp_elem      one pass over dW: with dA = dW M R (M = sa ca fa) and dlogit = dW M A R (1 - R/2) per element, the reductions
+//                dsa, dca, dfa (sums of dW R A times the two other factors), dka_g = <dA, Basis_g>,
+//                S_g = sum_b ka[b][g] dA[b] in the (3 cout, 3 cin) spatial layout of the spectrum's inverse transform,
+//                d loc_w[q][tau] = sum_b sum_i dlogit[b][q][i] ln[b][i + tau - pad], and
+//                G[b][tau][i] = sum_q dlogit[b][q][i] loc_w[q][tau]
 //   wp_dft_a/b   d dft_weight[r][c] = alpha w_c / (N1 N2) rfft2(S_{G(r,c)})[r][c]   (adjoint of the C2R transform: the
 //                same two-stage direct DFT as basis_stage_a/b, run the other way, only the bins of each group kept)
-//   wp_locw      d loc_w[q][tau] = sum_b sum_i dlogit[b][q][i] ln[b][i + tau - pad]
-//   wp_ln        d ln[b][j] = sum_q sum_tau dlogit[b][q][j - tau + pad] loc_w[q][tau], LayerNorm backward -> dpooled (local
-//                part), d ln_w, d ln_b
+//   wp_ln        d ln[b][j] = sum_tau G[b][tau][j - tau + pad], LayerNorm backward -> dpooled (local part), d ln_w, d ln_b
 //   wp_global    one workgroup for the batch: heads, StarReLU, BatchNorm (batch or running statistics), fc backward ->
 //                the KSM_Global parameter gradients and the global part of dpooled
 #include <math.h>
@@ -40,123 +40,143 @@ __device__ __forceinline__ float wp_wave_sum(float v) {
 }
 __device__ __forceinline__ float wp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// grid (cdiv(cin, 64), B, cdiv(cout, OPB)); 256 threads: lane <-> input channel, the four waves take output channels
-constexpr int OPB = 8;
-__global__ __launch_bounds__(256) void wp_elem(const float* __restrict__ dw, const float* __restrict__ mods, sr_layer_params lp,
-                                               float* __restrict__ dA, float* __restrict__ dlogit, float* __restrict__ dca,
-                                               float* __restrict__ dfa, float* __restrict__ dsa, float* __restrict__ dka) {
+// ---- wp_elem: everything that needs the per-element cotangent dW, in ONE pass over it -----------------------------------
+// grid (cdiv(cin, 64), cdiv(cout, 4), batch chunks); 256 threads: lane <-> input channel i, wave <-> output channel o.
+// A thread keeps, for its (o, i) and the nine taps, the four basis values, the KSM_Local weight rows and the accumulators
+// that run over the batch -- S_g (the spectrum's cotangent, sum_b ka[b][g] dA[b]) and d loc_w -- in registers; the
+// per-sample reductions (dca, dfa, dsa, dka, and G[b][tau][i] = sum_q dlogit[b][q][i] loc_w[q][tau], from which wp_ln forms
+// d ln) leave as one contiguous atomic instruction each.  (The first version wrote dA and dlogit to memory and reduced
+// them in three more kernels: 520 us per layer, mostly in two single-workgroup-per-sample loops.)
+template <int TAPS>
+__global__ __launch_bounds__(256) void wp_elem(const float* __restrict__ dw, const float* __restrict__ mods, sr_layer_params lp, int B,
+                                               int bchunk, float* __restrict__ S, float* __restrict__ dlocw, float* __restrict__ G,
+                                               float* __restrict__ dca, float* __restrict__ dfa, float* __restrict__ dsk) {
     __shared__ float red[4][64];
-    __shared__ float red13[4][16];
-    const int cin = lp.cin, cout = lp.cout, taps = lp.loc_taps, pad = (taps - 1) / 2;
+    constexpr int PAD = (TAPS - 1) / 2;
+    const int cin = lp.cin, cout = lp.cout;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
     const int i = blockIdx.x * 64 + lane;
     const bool live = i < cin;
     const int ic = live ? i : cin - 1;
-    const float* md = mods + (long)b * wp_mods_stride(cin, cout);
-    const float* ln = md + cin;
-    const float* fa = md + 2 * cin;
-    const float* sa = fa + cout;
-    const float* ka = sa + 9;
-    const float cav = md[ic];
-    float lnw[15];
-#pragma unroll
-    for (int t = 0; t < 15; ++t) {
-        const int j = ic + t - pad;
-        lnw[t] = (t < taps && j >= 0 && j < cin) ? ln[j] : 0.f;
-    }
-    float sav[9], kav[WKN];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) sav[t] = sa[t];
-#pragma unroll
-    for (int g = 0; g < WKN; ++g) kav[g] = ka[g];
-    float acc_ca = 0.f, acc_sa[9], acc_ka[WKN];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc_sa[t] = 0.f;
-#pragma unroll
-    for (int g = 0; g < WKN; ++g) acc_ka[g] = 0.f;
+    const int o = blockIdx.y * 4 + wave;
+    const bool olive = o < cout;          // wave-uniform
+    const int oc = olive ? o : cout - 1;
+    const int ms = wp_mods_stride(cin, cout);
     const long n = 9L * cout * cin;
-    const int o_end = min(cout, (int)(blockIdx.z + 1) * OPB);
-    for (int o = blockIdx.z * OPB + wave; o < o_end; o += 4) {
-        const float fav = fa[o];
-        float bs[WKN][9];
+    float bs[WKN][9], lw[9][TAPS];
 #pragma unroll
-        for (int g = 0; g < WKN; ++g)
+    for (int g = 0; g < WKN; ++g)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) bs[g][t] = lp.basis[(((long)g * cout + o) * cin + ic) * 9 + t];
-        float acc_fa = 0.f;
+        for (int t = 0; t < 9; ++t) bs[g][t] = lp.basis[(((long)g * cout + oc) * cin + ic) * 9 + t];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) lw[t][k] = lp.loc_w[(long)(oc * 9 + t) * TAPS + k];
+    float accS[WKN][9], accL[9][TAPS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int g = 0; g < WKN; ++g) accS[g][t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) accL[t][k] = 0.f;
+    }
+    const int b0 = blockIdx.z * bchunk, b1 = min(B, b0 + bchunk);
+    for (int b = b0; b < b1; ++b) {
+        const float* md = mods + (long)b * ms;
+        const float* ln = md + cin;
+        const float cav = md[ic], fav = md[2 * cin + oc];
+        float lnw[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const int j = ic + k - PAD;
+            lnw[k] = (j >= 0 && j < cin) ? ln[j] : 0.f;
+        }
+        float sav[9], kav[WKN];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sav[t] = md[2 * cin + cout + t];
+#pragma unroll
+        for (int g = 0; g < WKN; ++g) kav[g] = md[2 * cin + cout + 9 + g];
+        float a_ca = 0.f, a_fa = 0.f, a_sk[13], a_g[TAPS];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) a_sk[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) a_g[k] = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float* lw = lp.loc_w + (long)(o * 9 + t) * taps;
             float logit = 0.f;
 #pragma unroll
-            for (int k = 0; k < 15; ++k)
-                if (k < taps) logit += lw[k] * lnw[k];
+            for (int k = 0; k < TAPS; ++k) logit += lw[t][k] * lnw[k];
             const float R = 2.0f * wp_sigmoid(logit);
             float A = 0.f;
 #pragma unroll
             for (int g = 0; g < WKN; ++g) A += kav[g] * bs[g][t];
-            const long at = ((long)t * cout + o) * cin + ic;
-            const float d = live ? dw[(long)b * n + at] : 0.f;
+            const float d = (live && olive) ? dw[(long)b * n + ((long)t * cout + oc) * cin + ic] : 0.f;
             const float Q = d * R * A;
             const float M = sav[t] * cav * fav;
             const float dAv = d * M * R;
-            acc_sa[t] += Q * cav * fav;
-            acc_ca += Q * sav[t] * fav;
-            acc_fa += Q * sav[t] * cav;
+            const float dl = d * M * A * R * (1.0f - 0.5f * R);
+            a_sk[t] += Q * cav * fav;
+            a_ca += Q * sav[t] * fav;
+            a_fa += Q * sav[t] * cav;
 #pragma unroll
-            for (int g = 0; g < WKN; ++g) acc_ka[g] += dAv * bs[g][t];
-            if (live) {
-                dA[(long)b * n + at] = dAv;
-                dlogit[(long)b * n + ((long)(o * 9 + t)) * cin + i] = d * M * A * R * (1.0f - 0.5f * R);
+            for (int g = 0; g < WKN; ++g) {
+                a_sk[9 + g] += dAv * bs[g][t];
+                accS[g][t] += kav[g] * dAv;
+            }
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) {
+                accL[t][k] += dl * lnw[k];
+                a_g[k] += dl * lw[t][k];
             }
         }
-        acc_fa = wp_wave_sum(acc_fa);
-        if (lane == 0) atomicAdd(dfa + (long)b * cout + o, acc_fa);
-    }
-    red[wave][lane] = acc_ca;
+        // per-sample reductions.  Over the four output channels of the workgroup through LDS, then one atomic per lane:
+        // dca[b][i] and G[b][k][i] are contiguous over the lanes.
+        float v = a_ca;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float s = wp_wave_sum(acc_sa[t]);
-        if (lane == 0) red13[wave][t] = s;
-    }
+        for (int k = 0; k <= TAPS; ++k) {
+            __syncthreads();
+            red[wave][lane] = v;
+            __syncthreads();
+            if (wave == 0 && live) {
+                const float s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                if (k == 0) atomicAdd(dca + (long)b * cin + i, s);
+                else atomicAdd(G + ((long)b * TAPS + (k - 1)) * cin + i, s);
+            }
+            if (k < TAPS) v = a_g[k];
+        }
+        // dfa[b][o], dsa[b][0..8] | dka[b][0..3]: sums over the lanes; the 13 + 1 results leave as one atomic instruction
+        a_fa = wp_wave_sum(a_fa);
+        float mine = 0.f;
 #pragma unroll
-    for (int g = 0; g < WKN; ++g) {
-        const float s = wp_wave_sum(acc_ka[g]);
-        if (lane == 0) red13[wave][9 + g] = s;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        if (live) atomicAdd(dca + (long)b * cin + i, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
-        if (lane < 13) {
-            const float s = red13[0][lane] + red13[1][lane] + red13[2][lane] + red13[3][lane];
-            if (lane < 9) atomicAdd(dsa + (long)b * 12 + lane, s);
-            else atomicAdd(dka + (long)b * WKN + (lane - 9), s);
+        for (int j = 0; j < 13; ++j) {
+            const float s = wp_wave_sum(a_sk[j]);
+            if (lane == j) mine = s;
+        }
+        if (olive) {
+            if (lane < 13) atomicAdd(dsk + (long)b * 16 + lane, mine);
+            if (lane == 13) atomicAdd(dfa + (long)b * cout + o, a_fa);
         }
     }
-}
-
-// S[g][y = o*3+u][x = i*3+v] = sum_b ka[b][g] dA[b][t = u*3+v][o][i]
-__global__ __launch_bounds__(256) void wp_groupsum(const float* __restrict__ dA, const float* __restrict__ mods, int B, int cin,
-                                                   int cout, float* __restrict__ S) {
-    const long n = 9L * cout * cin;
-    const long e = blockIdx.x * 256L + threadIdx.x;
-    if (e >= n) return;
-    const int i = (int)(e % cin);
-    const int o = (int)((e / cin) % cout);
-    const int t = (int)(e / ((long)cin * cout));
-    const int ms = wp_mods_stride(cin, cout);
-    float acc[WKN] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) {
-        const float d = dA[(long)b * n + e];
-        const float* ka = mods + (long)b * ms + 2 * cin + cout + 9;
-#pragma unroll
-        for (int g = 0; g < WKN; ++g) acc[g] += ka[g] * d;
-    }
+    if (!olive) return;
+    // sums over the batch: S[g][y = o*3+u][x = i*3+v] (t = u*3+v), d loc_w[o*9+t][k]
     const int N2 = 3 * cin;
-    const long at = (long)(o * 3 + t / 3) * N2 + i * 3 + t % 3;
+    if (live) {
 #pragma unroll
-    for (int g = 0; g < WKN; ++g) S[(long)g * 9 * cout * cin + at] = acc[g];
+        for (int g = 0; g < WKN; ++g)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                atomicAdd(S + (long)g * n + (long)(o * 3 + t / 3) * N2 + i * 3 + t % 3, accS[g][t]);
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const float s = wp_wave_sum(accL[t][k]);
+            if (lane == t * TAPS + k) mine = s;
+        }
+    static_assert(9 * TAPS <= 64, "one atomic instruction per wave");
+    if (lane < 9 * TAPS) atomicAdd(dlocw + (long)o * 9 * TAPS + lane, mine);
 }
 
 constexpr int WP_TW = 2048;
@@ -221,51 +241,17 @@ __global__ __launch_bounds__(256) void wp_dft_b(const float2* __restrict__ T, co
     }
 }
 
-// d loc_w[q][tau]: one wavefront per q, lanes over the input channels
-__global__ __launch_bounds__(256) void wp_locw(const float* __restrict__ dlogit, const float* __restrict__ mods, int B, int cin,
-                                               int cout, int taps, float* __restrict__ dlocw) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= cout * 9) return;
-    const int pad = (taps - 1) / 2, ms = wp_mods_stride(cin, cout);
-    const long n = 9L * cout * cin;
-    float acc[15];
-#pragma unroll
-    for (int k = 0; k < 15; ++k) acc[k] = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* ln = mods + (long)b * ms + cin;
-        const float* dl = dlogit + (long)b * n + (long)q * cin;
-        for (int i = lane; i < cin; i += 64) {
-            const float d = dl[i];
-#pragma unroll
-            for (int k = 0; k < 15; ++k) {
-                const int j = i + k - pad;
-                if (k < taps && j >= 0 && j < cin) acc[k] += d * ln[j];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-        if (k < taps) {
-            const float s = wp_wave_sum(acc[k]);
-            if (lane == 0) dlocw[(long)q * taps + k] = s;
-        }
-    }
-}
-
-// one workgroup per sample: d ln, LayerNorm backward
-__global__ __launch_bounds__(256) void wp_ln(const float* __restrict__ dlogit, const float* __restrict__ pooled, int pooled_ld,
-                                             sr_layer_params lp, float* __restrict__ dpooled, int dpooled_ld,
-                                             float* __restrict__ dlnw, float* __restrict__ dlnb) {
+// one workgroup per sample: d ln[j] = sum_tau G[b][tau][j - tau + pad], then LayerNorm backward
+__global__ __launch_bounds__(256) void wp_ln(const float* __restrict__ G, const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp,
+                                             float* __restrict__ dpooled, int dpooled_ld, int acc, float* __restrict__ dlnw,
+                                             float* __restrict__ dlnb) {
     extern __shared__ float sh[];  // dnhat[cin] | nhat[cin] | red[8]
-    const int cin = lp.cin, cout = lp.cout, taps = lp.loc_taps, pad = (taps - 1) / 2;
+    const int cin = lp.cin, taps = lp.loc_taps, pad = (taps - 1) / 2;
     float* dn = sh;
     float* nh = sh + cin;
     float* red = nh + cin;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = pooled + (long)b * pooled_ld;
-    const long n = 9L * cout * cin;
-    // statistics of the sample (biased variance, eps 1e-5, as the forward)
     float s = 0.f;
     for (int i = tid; i < cin; i += 256) s += p[i];
     s = wp_wave_sum(s);
@@ -283,13 +269,9 @@ __global__ __launch_bounds__(256) void wp_ln(const float* __restrict__ dlogit, c
     float m1 = 0.f, m2 = 0.f;
     for (int j = tid; j < cin; j += 256) {
         float acc = 0.f;
-        for (int q = 0; q < cout * 9; ++q) {
-            const float* dl = dlogit + (long)b * n + (long)q * cin;
-            const float* lw = lp.loc_w + (long)q * taps;
-            for (int k = 0; k < taps; ++k) {
-                const int i = j - k + pad;  // output position whose window holds ln[j] at tap k
-                if (i >= 0 && i < cin) acc += dl[i] * lw[k];
-            }
+        for (int k = 0; k < taps; ++k) {
+            const int i = j - k + pad;  // output position whose window holds ln[j] at tap k
+            if (i >= 0 && i < cin) acc += G[((long)b * taps + k) * cin + i];
         }
         const float nhat = (p[j] - mean) * rstd;
         atomicAdd(dlnw + j, acc * nhat);
@@ -308,24 +290,40 @@ __global__ __launch_bounds__(256) void wp_ln(const float* __restrict__ dlogit, c
     }
     __syncthreads();
     const float a1 = (red[0] + red[1] + red[2] + red[3]) / cin, a2 = (red[4] + red[5] + red[6] + red[7]) / cin;
-    for (int j = tid; j < cin; j += 256) dpooled[(long)b * dpooled_ld + j] = rstd * (dn[j] - a1 - nh[j] * a2);
+    for (int j = tid; j < cin; j += 256) {
+        float* d = dpooled + (long)b * dpooled_ld + j;
+        *d = rstd * (dn[j] - a1 - nh[j] * a2) + (acc ? *d : 0.f);
+    }
 }
 
-// KSM_Global backward, one workgroup for the whole batch (BatchNorm couples the samples in train mode)
+// KSM_Global backward, one workgroup for the whole batch (BatchNorm couples the samples in train mode).
+// dpre: global scratch [B][per] for the pre-sigmoid gradients of the four heads (recomputing them inside the two loops that
+// use them cost 3 dependent loads per term: 129 us per layer)
 template <bool TRAIN>
 __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp, int B,
                                                   const float* __restrict__ mods, const float* __restrict__ dca,
-                                                  const float* __restrict__ dfa, const float* __restrict__ dsa,
-                                                  const float* __restrict__ dka, WpGrads g, float* __restrict__ dpooled,
-                                                  int dpooled_ld) {
+                                                  const float* __restrict__ dfa, const float* __restrict__ dsk, float* __restrict__ dpre,
+                                                  WpGrads g, float* __restrict__ dpooled, int dpooled_ld) {
     extern __shared__ float sh[];
     const int cin = lp.cin, cout = lp.cout, ms = wp_mods_stride(cin, cout);
     float* zh = sh;                 // [B][ATT] normalised fc outputs
     float* rr = zh + B * WATT;      // relu(u)
     float* av = rr + B * WATT;      // StarReLU output a
     float* dz = av + B * WATT;      // da -> du -> dz
-    float* stat = dz + B * WATT;    // mean[16] | rstd[16] | scratch[32]
+    float* stat = dz + B * WATT;    // mean[16] | rstd[16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    const int per = cin + cout + 9 + WKN;
+    // pre-sigmoid gradients:  ca, fa, sa = 2 sigmoid(v): d/dv = y (1 - y/2);  ka = 2/KN sigmoid(v): d/dv = y (1 - y KN / 2)
+    for (int it = tid; it < B * per; it += nt) {
+        const int b = it / per, j = it - b * per;
+        const float* md = mods + (long)b * ms;
+        float v;
+        if (j < cin) { const float y = md[j]; v = dca[(long)b * cin + j] * y * (1.0f - 0.5f * y); }
+        else if (j < cin + cout) { const int r = j - cin; const float y = md[2 * cin + r]; v = dfa[(long)b * cout + r] * y * (1.0f - 0.5f * y); }
+        else if (j < cin + cout + 9) { const int r = j - cin - cout; const float y = md[2 * cin + cout + r]; v = dsk[(long)b * 16 + r] * y * (1.0f - 0.5f * y); }
+        else { const int r = j - cin - cout - 9; const float y = md[2 * cin + cout + 9 + r]; v = dsk[(long)b * 16 + 9 + r] * y * (1.0f - 0.5f * WKN * y); }
+        dpre[it] = v;
+    }
     for (int pair = wave; pair < B * WATT; pair += nw) {
         const int b = pair / WATT, k = pair - b * WATT;
         const float* p = pooled + (long)b * pooled_ld;
@@ -335,6 +333,7 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
         s = wp_wave_sum(s);
         if (lane == 0) zh[pair] = s;
     }
+    __threadfence_block();
     __syncthreads();
     if (tid < WATT) {
         float m, var;
@@ -363,38 +362,28 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
         av[i] = s0 * r * r + lp.relu_b[0];
     }
     __syncthreads();
-    // pre-sigmoid gradients of the four heads, recomputed wherever they are used:
-    //   ca, fa, sa = 2 sigmoid(v): d/dv = y (1 - y/2);  ka = 2/KN sigmoid(v): d/dv = y (1 - y KN / 2)
-    const int per = cin + cout + 9 + WKN;
-    auto dpre = [&](int b, int j) -> float {
-        const float* md = mods + (long)b * ms;
-        if (j < cin) { const float y = md[j]; return dca[(long)b * cin + j] * y * (1.0f - 0.5f * y); }
-        if (j < cin + cout) { const int r = j - cin; const float y = md[2 * cin + r]; return dfa[(long)b * cout + r] * y * (1.0f - 0.5f * y); }
-        if (j < cin + cout + 9) { const int r = j - cin - cout; const float y = md[2 * cin + cout + r]; return dsa[(long)b * 12 + r] * y * (1.0f - 0.5f * y); }
-        const int r = j - cin - cout - 9;
-        const float y = md[2 * cin + cout + 9 + r];
-        return dka[(long)b * WKN + r] * y * (1.0f - 0.5f * WKN * y);
-    };
+    // the four heads as one [per][ATT] matrix: row j -> (weights, gradient destinations)
     auto head = [&](int j, const float*& w, float*& gw, float*& gb, int& row) {
         if (j < cin) { row = j; w = lp.ch_w; gw = g.ch_w; gb = g.ch_b; }
         else if (j < cin + cout) { row = j - cin; w = lp.fl_w; gw = g.fl_w; gb = g.fl_b; }
         else if (j < cin + cout + 9) { row = j - cin - cout; w = lp.sp_w; gw = g.sp_w; gb = g.sp_b; }
         else { row = j - cin - cout - 9; w = lp.kn_w; gw = g.kn_w; gb = g.kn_b; }
     };
-    // da[b][k] = sum_rows dpre[b][row] W[row][k]
-    for (int i = tid; i < B * WATT; i += nt) {
-        const int b = i / WATT, k = i - b * WATT;
+    // da[b][k] = sum_rows dpre[b][row] W[row][k]: one wavefront per (b, k) pair, lanes over the rows
+    for (int pair = wave; pair < B * WATT; pair += nw) {
+        const int b = pair / WATT, k = pair - b * WATT;
         float s = 0.f;
-        for (int j = 0; j < per; ++j) {
+        for (int j = lane; j < per; j += 64) {
             const float* w;
             float *gw, *gb;
             int row;
             head(j, w, gw, gb, row);
-            s += dpre(b, j) * w[row * WATT + k];
+            s += dpre[(long)b * per + j] * w[row * WATT + k];
         }
-        dz[i] = s;
+        s = wp_wave_sum(s);
+        if (lane == 0) dz[pair] = s;
     }
-    // head weight / bias gradients
+    // head weight / bias gradients: one thread per (row, k)
     for (int i = tid; i < per * WATT; i += nt) {
         const int j = i / WATT, k = i - j * WATT;
         const float* w;
@@ -403,7 +392,7 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
         head(j, w, gw, gb, row);
         float s = 0.f, sb = 0.f;
         for (int b = 0; b < B; ++b) {
-            const float d = dpre(b, j);
+            const float d = dpre[(long)b * per + j];
             s += d * av[b * WATT + k];
             sb += d;
         }
@@ -459,20 +448,22 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
 }
 
 struct WpLayout {
-    size_t dA, dlogit, S, T, red, total;
-    size_t red_floats;
+    size_t S, T, red, dpre, total;
+    size_t S_floats, red_floats;
 };
-static WpLayout wp_layout(int B, int cin, int cout) {
+// S [4][9 cout cin] | T [4][3 cout][3 cin / 2 + 1] complex | reductions: G [B][taps][cin], dca [B][cin], dfa [B][cout],
+// dsa|dka [B][16] (S and the reductions start from zero: one memset) | dpre [B][cin + cout + 13]
+static WpLayout wp_layout(int B, int cin, int cout, int taps) {
     WpLayout l{};
     const size_t n = 9ul * cout * cin;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    l.dA = carve((size_t)B * n * 4);
-    l.dlogit = carve((size_t)B * n * 4);
-    l.S = carve((size_t)WKN * n * 4);
-    l.T = carve((size_t)WKN * 3 * cout * (3 * cin / 2 + 1) * 8);
-    l.red_floats = (size_t)B * (cin + cout + 12 + WKN);
+    l.S_floats = (size_t)WKN * n;
+    l.S = carve(l.S_floats * 4);
+    l.red_floats = (size_t)B * ((size_t)taps * cin + cin + cout + 16);
     l.red = carve(l.red_floats * 4);
+    l.T = carve((size_t)WKN * 3 * cout * (3 * cin / 2 + 1) * 8);
+    l.dpre = carve((size_t)B * (cin + cout + 9 + WKN) * 4);
     l.total = off;
     return l;
 }
@@ -482,16 +473,16 @@ using namespace sr;
 
 extern "C" size_t sr_fdconv_weightgen_backward_workspace_bytes(int B, int cin, int cout) {
     if (B < 1 || cin < 1 || cout < 1) return 0;
-    return wp_layout(B, cin, cout).total;
+    return wp_layout(B, cin, cout, 7).total;  // (taps <= 7: checked by the call)
 }
 
 extern "C" int sr_fdconv_weightgen_backward(int B, const float* pooled, int pooled_ld, const sr_layer_params* lp, int train,
                                             const float* mods, const float* dft_weight, const uint8_t* gmap, float alpha,
                                             const float* dw, const sr_weight_path_grads* grads, float* dpooled, int dpooled_ld,
-                                            void* workspace, size_t workspace_bytes, void* stream) {
+                                            int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     (void)dft_weight;  // the spectrum enters through lp->basis; its gradient does not depend on its value beyond that
     SR_REQUIRE(B > 0 && B <= 512 && pooled && lp && mods && gmap && dw && grads && dpooled && workspace);
-    SR_REQUIRE(lp->cin > 0 && lp->cout > 0 && lp->cin <= 4096 && lp->cout <= 4096 && lp->loc_taps >= 1 && (lp->loc_taps & 1) && lp->loc_taps <= 15);
+    SR_REQUIRE(lp->cin > 0 && lp->cout > 0 && lp->cin <= 4096 && lp->cout <= 4096 && lp->loc_taps >= 1 && (lp->loc_taps & 1) && lp->loc_taps <= 7);
     SR_REQUIRE(lp->basis && lp->fc_w && lp->bn_w && lp->bn_b && lp->bn_rm && lp->bn_rv && lp->relu_s && lp->relu_b && lp->ch_w && lp->fl_w &&
                lp->sp_w && lp->kn_w && lp->loc_w && lp->ln_w && lp->ln_b);
     SR_REQUIRE(pooled_ld >= lp->cin && dpooled_ld >= lp->cin && (3 * lp->cin) % 2 == 0);
@@ -500,46 +491,58 @@ extern "C" int sr_fdconv_weightgen_backward(int B, const float* pooled, int pool
     for (size_t i = 0; i < sizeof(sr_weight_path_grads) / sizeof(float*); ++i) SR_REQUIRE(gp[i] != nullptr);
     const int cin = lp->cin, cout = lp->cout;
     SR_REQUIRE(3 * cin <= WP_TW && 3 * cout <= WP_TW);
-    const WpLayout l = wp_layout(B, cin, cout);
+    const int taps = lp->loc_taps;
+    SR_REQUIRE(taps <= 7);  // KSM_Local's kernel: 5 taps for 16 <= cin < 512, 7 up to 2048 (FDConv.py:282-284)
+    const WpLayout l = wp_layout(B, cin, cout, taps);
     if (workspace_bytes < l.total) return SR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    float* dA = (float*)(ws + l.dA);
-    float* dlogit = (float*)(ws + l.dlogit);
     float* S = (float*)(ws + l.S);
     float2* T = (float2*)(ws + l.T);
-    float* dca = (float*)(ws + l.red);
+    float* G = (float*)(ws + l.red);
+    float* dca = G + (size_t)B * taps * cin;
     float* dfa = dca + (size_t)B * cin;
-    float* dsa = dfa + (size_t)B * cout;
-    float* dka = dsa + (size_t)B * 12;
+    float* dsk = dfa + (size_t)B * cout;
+    float* dpre = (float*)(ws + l.dpre);
     WpGrads g;
     static_assert(sizeof(WpGrads) == sizeof(sr_weight_path_grads), "grads struct");
     ::memcpy(&g, grads, sizeof(g));
     const long n = 9L * cout * cin;
     const int N1 = 3 * cout, N2 = 3 * cin, n2h = N2 / 2 + 1;
-    SR_HIP(hipMemsetAsync(dca, 0, l.red_floats * 4, st));
+    // S and the reductions are adjacent: one memset (l.red follows l.S up to alignment padding)
+    SR_HIP(hipMemsetAsync(S, 0, (l.red - l.S) + l.red_floats * 4, st));
+    SR_HIP(hipMemsetAsync(g.loc_w, 0, (size_t)cout * 9 * taps * 4, st));
     SR_HIP(hipMemsetAsync(g.ln_w, 0, (size_t)cin * 4, st));
     SR_HIP(hipMemsetAsync(g.ln_b, 0, (size_t)cin * 4, st));
-    wp_elem<<<dim3(cdiv(cin, 64), B, cdiv(cout, OPB)), 256, 0, st>>>(dw, mods, *lp, dA, dlogit, dca, dfa, dsa, dka);
+    // batch chunks: enough workgroups to fill the chip, as few atomic rounds on S / d loc_w as that allows
+    const int wgs = cdiv(cin, 64) * cdiv(cout, 4);
+    int nz = (512 + wgs - 1) / wgs;
+    if (nz > B) nz = B;
+    if (nz < 1) nz = 1;
+    const int bchunk = cdiv(B, nz);
+    const dim3 ge(cdiv(cin, 64), cdiv(cout, 4), cdiv(B, bchunk));
+#define SR_WPE(TAPS_) wp_elem<TAPS_><<<ge, 256, 0, st>>>(dw, mods, *lp, B, bchunk, S, g.loc_w, G, dca, dfa, dsk)
+    if (taps == 1) SR_WPE(1);
+    else if (taps == 3) SR_WPE(3);
+    else if (taps == 5) SR_WPE(5);
+    else SR_WPE(7);
+#undef SR_WPE
     SR_LAUNCH_CHECK();
-    wp_groupsum<<<cdiv(n, 256), 256, 0, st>>>(dA, mods, B, cin, cout, S);
-    SR_LAUNCH_CHECK();
+    (void)n;
     const long na = (long)WKN * N1 * n2h, nb = (long)N1 * n2h;
     wp_dft_a<<<cdiv(na, 256), 256, 0, st>>>(S, N1, N2, T);
     SR_LAUNCH_CHECK();
     wp_dft_b<<<cdiv(nb, 256), 256, 0, st>>>(T, gmap, alpha, N1, N2, g.dft);
     SR_LAUNCH_CHECK();
-    wp_locw<<<cdiv(cout * 9, 4), 256, 0, st>>>(dlogit, mods, B, cin, cout, lp->loc_taps, g.loc_w);
-    SR_LAUNCH_CHECK();
-    wp_ln<<<B, 256, (2 * (size_t)cin + 8) * 4, st>>>(dlogit, pooled, pooled_ld, *lp, dpooled, dpooled_ld, g.ln_w, g.ln_b);
+    wp_ln<<<B, 256, (2 * (size_t)cin + 8) * 4, st>>>(G, pooled, pooled_ld, *lp, dpooled, dpooled_ld, accumulate, g.ln_w, g.ln_b);
     SR_LAUNCH_CHECK();
     const size_t shg = ((size_t)4 * B * WATT + 64) * 4;
     if (train) {
         SR_LDS_ATTR(shg, wp_global<true>);
-        wp_global<true><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsa, dka, g, dpooled, dpooled_ld);
+        wp_global<true><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsk, dpre, g, dpooled, dpooled_ld);
     } else {
         SR_LDS_ATTR(shg, wp_global<false>);
-        wp_global<false><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsa, dka, g, dpooled, dpooled_ld);
+        wp_global<false><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsk, dpre, g, dpooled, dpooled_ld);
     }
     SR_LAUNCH_CHECK();
     return SR_OK;
