@@ -399,8 +399,8 @@ def run_train(args, world, rank, dev, dist):
     """BASELINE.json configs[3]: one optimisation step of RRDBNet-FDConv(1,1,64,23,32) shaped as
     train/train_realESRGAN_fdconv_1.py:110-118 -- forward in train() mode, bilinear resize to the HR size + L1, backward,
     gradient all-reduce over the ranks (RCCL), Adam -- on `--train-batch` HR crops of 256x256 per GPU (LR = 4x area
-    downsample), float32 (stage 1 of the training path: fp32 kernels, no MFMA yet).  The perceptual (VGG19) term of the
-    Real-ESRGAN recipe is basicsr framework code outside SURVEY section 8 and is not part of the owner's script."""
+    downsample), mixed precision by default.  Loss: L1 + the perceptual (VGG19-feature) term of the Real-ESRGAN recipe
+    (--train-loss l1: the owner script's L1 alone)."""
     from super_resolution_amd import RRDBNet, replace_conv_with_fdconv, train as T
     # the network as the owner script builds it (train_realESRGAN_fdconv_1.py:100-102): RRDBNet's own initialisation, every
     # conv swapped for a freshly initialised FDConv.  (The O(1)-perturbed parameter set of the inference configs makes the
@@ -420,6 +420,13 @@ def run_train(args, world, rank, dev, dist):
     # Adam over one flat buffer (same update rule as torch.optim.Adam(lr=1e-4) of the owner script; tests/test_cpu_host.py):
     # one gather, one all-reduce, five tensor ops per step instead of a walk over ~6000 parameter tensors
     opt = T.FlatAdam(net.parameters(), lr=1e-4)
+    # BASELINE configs[3]: "L1 + perceptual".  Perceptual term as SURVEY 8(d) cfg4 prescribes: VGG19-shaped extractor, seeded
+    # random initialisation (pretrained weights are a network fetch), features before ReLU at conv{1_2,2_2,3_4,4_4,5_4} with
+    # weights {0.1,0.1,1,1,1} (options/train_realesrgan_x4plus.yml:133-149); --train-loss l1 = the owner script's loss alone
+    perc = None
+    if args.train_loss == 'l1+perceptual':
+        from super_resolution_amd.perceptual import VGG19Features
+        perc = dict(vgg=VGG19Features(seed=1234).to(dev), compute_dtype=torch.bfloat16 if mixed else torch.float32)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -429,11 +436,11 @@ def run_train(args, world, rank, dev, dist):
 
     losses = []
     for _ in range(max(args.warmup, 1)):
-        losses.append(float(T.train_step(net, opt, wf, sr)))
+        losses.append(float(T.train_step(net, opt, wf, sr, perceptual=perc)))
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = T.train_step(net, opt, wf, sr)
+        loss = T.train_step(net, opt, wf, sr, perceptual=perc)
     sync()
     elapsed = time.perf_counter() - t0
     losses.append(float(loss))
@@ -449,9 +456,11 @@ def run_train(args, world, rank, dev, dist):
         'warmup': max(args.warmup, 1), 'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if mixed else 'f32', 'data': 'synthetic',
         'config': {'workload': 'training step of RRDBNet-FDConv(1,1,64,23,32): %d HR crops of %dx%d per GPU (LR %dx%d), train-mode '
-                               'forward + bilinear/L1 loss + backward + gradient all-reduce + Adam (train.FlatAdam: one flat buffer), %s '
-                               '(BASELINE.json configs[3], L1 term of the owner script)'
-                               % (B, hr, hr, lr_side, lr_side, 'bf16 activations on MFMA, float32 parameters / weight gradients / Adam' if mixed else 'float32'),
+                               'forward + %s loss + backward + gradient all-reduce + Adam (train.FlatAdam: one flat buffer), %s '
+                               '(BASELINE.json configs[3])'
+                               % (B, hr, hr, lr_side, lr_side,
+                                  'bilinear/L1 + perceptual (seeded random-init VGG19 features, yml weights)' if perc else 'bilinear/L1 (owner script)',
+                                  'bf16 activations on MFMA, float32 parameters / weight gradients / Adam' if mixed else 'float32'),
                    'global_batch': world * B, 'samples_per_s': world * B / step_s,
                    'parallelism': 'data parallel x%d, one all-reduce over the flat %.1f M-parameter gradient buffer per step (local BatchNorm statistics)' % (world, nparam / 1e6),
                    'loss_first_last': [losses[0], losses[-1]], 'loss_finite': bool(np.isfinite(losses).all()),
@@ -473,6 +482,7 @@ def main():
     ap.add_argument('--train-batch', type=int, default=32, help='train: HR crops per GPU and step')
     ap.add_argument('--train-hr', type=int, default=256, help='train: side of the HR crops')
     ap.add_argument('--train-dtype', choices=('bf16', 'f32'), default='bf16', help='train: bf16 = mixed precision (bf16 activations on the matrix cores, float32 parameters and weight gradients); f32 = the parity path')
+    ap.add_argument('--train-loss', choices=('l1+perceptual', 'l1'), default='l1+perceptual', help='train: BASELINE configs[3] says L1 + perceptual; l1 = the owner script (train_realESRGAN_fdconv_1.py:116)')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')

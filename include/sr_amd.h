@@ -226,6 +226,28 @@ size_t sr_resize_l1_workspace_bytes(void);
 int sr_resize_l1_loss(const float* pred, const float* target, long planes, int Hs, int Ws, int Hd, int Wd, int weighted,
                       int pre_sigmoid, float* loss, float* grad_pred, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- perceptual (VGG-feature L1) loss of the Real-ESRGAN recipe -------------------------------------------------------
+ * (Real-ESRGAN-master/options/train_realesrgan_x4plus.yml:133-149: basicsr PerceptualLoss, vgg19, features before ReLU at
+ * conv1_2, conv2_2, conv3_4, conv4_4, conv5_4 with weights 0.1, 0.1, 1, 1, 1, criterion l1, use_input_norm; BASELINE
+ * configs[3]).  The 3x3 convolutions of the extractor run on sr_conv3x3 (forward and, with transposed weights, backward:
+ * the extractor is frozen, so no weight gradient exists); these are the pieces between them, all on contiguous NHWC
+ * tensors in `dtype`:
+ *   sr_relu_pool           dst (B,Ho,Wo,C) = max_pool2d(relu(src (B,Ho*pool,Wo*pool,C)), pool), pool = 1 (ReLU only) or 2
+ *   sr_relu_pool_backward  dx = its backward at src given dy (+ `add`, may be NULL: a tapped layer's own loss gradient)
+ *   sr_l1_feature_loss     *loss += weight * mean|a - b| (float atomics); grad_a (may be NULL) = weight * sign(a - b) / n
+ *   sr_vgg_prep            adjoint = 0: src float image (B,Cs,H,W), Cs = 1 (grey, repeated to RGB) or 3 -> dst (B,H,W,3)
+ *                          in dtype, (x - mean[c]) / std[c] (use_input_norm; both NULL: no normalisation);
+ *                          adjoint != 0: dst holds the gradient (B,H,W,3), src RECEIVES the float gradient (B,Cs,H,W)
+ *   sr_bilinear_resize_backward  adjoint of sr_bilinear_resize (float32): dsrc (planes,Hs,Ws) OVERWRITTEN from ddst
+ *                          (planes,Hd,Wd) -- the perceptual term is taken on the prediction resized to the target's size. */
+int sr_relu_pool(int dtype, int B, int Ho, int Wo, int C, int pool, const void* src, void* dst, void* stream);
+int sr_relu_pool_backward(int dtype, int B, int Ho, int Wo, int C, int pool, const void* src, const void* dy, const void* add, void* dx,
+                          void* stream);
+int sr_l1_feature_loss(int dtype, long n, const void* a, const void* b, float weight, float* loss, void* grad_a, void* stream);
+int sr_vgg_prep(int dtype, int B, int Cs, int H, int W, const float* src, void* dst, const float* mean3, const float* std3, int adjoint,
+                void* stream);
+int sr_bilinear_resize_backward(const float* ddst, float* dsrc, long planes, int Hs, int Ws, int Hd, int Wd, void* stream);
+
 /* RealESRGANer.enhance's image ends (Real-ESRGAN-master/realesrgan/utils.py:197-216 and :225-254), so that the
  * host <-> device transfers carry the INTEGER image (a 16384^2 RGB result is 0.8 GB as uint8, 3.2 GB as float32):
  * sr_image_to_planes: src (H,W,channels) HWC device image, src_kind 0 = uint8, 1 = uint16, 2 = float32 ->

@@ -9,6 +9,6 @@ from .fdconv import FDConv, replace_conv_with_fdconv  # noqa: F401
 from .rrdbnet import RRDBNet  # noqa: F401
 from .realesrganer import RealESRGANer  # noqa: F401
 from .srvgg import SRVGGNetCompact  # noqa: F401
-from . import convert, head, train  # noqa: F401
+from . import convert, head, perceptual, train  # noqa: F401
 
 __all__ = ['FDConv', 'RRDBNet', 'RealESRGANer', 'SRVGGNetCompact', 'replace_conv_with_fdconv']

@@ -104,6 +104,13 @@ _SIGS = {
     'sr_resize_l1_workspace_bytes': (C.c_size_t, []),
     'sr_resize_l1_loss': (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_relu_pool': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_relu_pool_backward': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    'sr_l1_feature_loss': (C.c_int, [C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_vgg_prep': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                              C.c_int, C.c_void_p]),
+    'sr_bilinear_resize_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_image_to_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                      C.c_void_p]),
     'sr_image_from_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -161,6 +161,124 @@ __global__ void image_from_planes_kernel(const TS* __restrict__ src, int H, int 
     }
 }
 
+// ---- perceptual (VGG-feature L1) loss: the pieces between the 3x3 convolutions ---------------------------------------
+// relu + 2x2 max-pool (pool = 1: relu only) on NHWC tensors, and its backward: the gradient goes to the first maximum of
+// the window in scan order (torch's max_pool2d) where the pre-activation is positive
+template <typename T>
+__global__ __launch_bounds__(256) void relu_pool_kernel(int B, int Ho, int Wo, int C, int pool, const T* __restrict__ src, T* __restrict__ dst) {
+    const int Hs = Ho * pool, Ws = Wo * pool;
+    const long n = (long)B * Ho * Wo * C;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int w = (int)(r % Wo);
+        r /= Wo;
+        const int h = (int)(r % Ho), b = (int)(r / Ho);
+        float m = 0.f;
+        for (int dy = 0; dy < pool; ++dy)
+            for (int dx = 0; dx < pool; ++dx)
+                m = fmaxf(m, Elem<T>::ld(src + (((long)b * Hs + h * pool + dy) * Ws + w * pool + dx) * C + c));
+        Elem<T>::st(dst + e, m);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void relu_pool_bwd_kernel(int B, int Ho, int Wo, int C, int pool, const T* __restrict__ src,
+                                                            const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dx) {
+    const int Hs = Ho * pool, Ws = Wo * pool;
+    const long n = (long)B * Ho * Wo * C;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int w = (int)(r % Wo);
+        r /= Wo;
+        const int h = (int)(r % Ho), b = (int)(r / Ho);
+        const float g = Elem<T>::ld(dy + e);
+        float m = -INFINITY;
+        int at = 0;
+        for (int k = 0; k < pool * pool; ++k) {
+            const float v = Elem<T>::ld(src + (((long)b * Hs + h * pool + k / pool) * Ws + w * pool + k % pool) * C + c);
+            if (v > m) { m = v; at = k; }
+        }
+        for (int k = 0; k < pool * pool; ++k) {
+            const long o = (((long)b * Hs + h * pool + k / pool) * Ws + w * pool + k % pool) * C + c;
+            float v = (k == at && m > 0.f) ? g : 0.f;
+            if (add) v += Elem<T>::ld(add + o);   // a tapped layer's own loss gradient
+            Elem<T>::st(dx + o, v);
+        }
+    }
+}
+// loss += weight * mean |a - b|;  grad (may be null) = weight * sign(a - b) / n
+template <typename T>
+__global__ __launch_bounds__(256) void l1_feature_kernel(long n, const T* __restrict__ a, const T* __restrict__ b, float weight,
+                                                         float* __restrict__ loss, T* __restrict__ grad) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    const float gs = weight / (float)n;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float d = Elem<T>::ld(a + e) - Elem<T>::ld(b + e);
+        acc += fabsf(d);
+        if (grad) Elem<T>::st(grad + e, d > 0.f ? gs : (d < 0.f ? -gs : 0.f));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss, red[0] * gs);
+}
+// (x - mean[c]) / std[c] of a (B, Cs, H, W) float image, Cs = 1 (grey, repeated) or 3, into NHWC 3 channels; and its adjoint
+template <typename T>
+__global__ __launch_bounds__(256) void vgg_prep_kernel(int B, int Cs, long npix, const float* __restrict__ src, T* __restrict__ dst,
+                                                       float m0, float m1, float m2, float s0, float s1, float s2, int norm) {
+    const long n = (long)B * npix;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long b = e / npix, p = e - b * npix;
+        const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+        for (int c = 0; c < 3; ++c) {
+            float v = src[(b * Cs + (Cs == 1 ? 0 : c)) * npix + p];
+            if (norm) v = (v - mean[c]) / sd[c];
+            Elem<T>::st(dst + e * 3 + c, v);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void vgg_prep_bwd_kernel(int B, int Cs, long npix, const T* __restrict__ dy, float* __restrict__ dsrc,
+                                                           float s0, float s1, float s2, int norm) {
+    const long n = (long)B * npix;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long b = e / npix, p = e - b * npix;
+        const float sd[3] = {s0, s1, s2};
+        float g[3];
+        for (int c = 0; c < 3; ++c) g[c] = Elem<T>::ld(dy + e * 3 + c) / (norm ? sd[c] : 1.0f);
+        if (Cs == 1) dsrc[b * npix + p] = g[0] + g[1] + g[2];
+        else
+            for (int c = 0; c < 3; ++c) dsrc[(b * 3 + c) * npix + p] = g[c];
+    }
+}
+// adjoint of bilinear_resize_kernel (float32): dsrc (zeroed by the caller) += weights * ddst
+__global__ __launch_bounds__(256) void bilinear_resize_bwd_kernel(const float* __restrict__ ddst, float* __restrict__ dsrc, long planes, int Hs,
+                                                                  int Ws, int Hd, int Wd) {
+    const long n = planes * Hd * Wd;
+    const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % Wd);
+        long t = i / Wd;
+        const int y = (int)(t % Hd);
+        const long p = t / Hd;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_taps(y, sh, Hs, y0, y1, ly);
+        bilinear_taps(x, sw, Ws, x0, x1, lx);
+        const float g = ddst[i];
+        float* gp = dsrc + p * Hs * Ws;
+        atomicAdd(gp + (long)y0 * Ws + x0, g * (1.f - ly) * (1.f - lx));
+        atomicAdd(gp + (long)y0 * Ws + x1, g * (1.f - ly) * lx);
+        atomicAdd(gp + (long)y1 * Ws + x0, g * ly * (1.f - lx));
+        atomicAdd(gp + (long)y1 * Ws + x1, g * ly * lx);
+    }
+}
+
 static int head_grid(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -250,6 +368,70 @@ extern "C" int sr_image_from_planes(const void* src, int src_dtype, int H, int W
     else if (sixteen) SR_IM(bf16_t, uint16_t);
     else SR_IM(bf16_t, uint8_t);
 #undef SR_IM
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_relu_pool(int dtype, int B, int Ho, int Wo, int C, int pool, const void* src, void* dst, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && Ho > 0 && Wo > 0 && C > 0 && (pool == 1 || pool == 2) && src && dst);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid((long)B * Ho * Wo * C);
+    if (dtype == SR_F32) relu_pool_kernel<float><<<g, 256, 0, st>>>(B, Ho, Wo, C, pool, (const float*)src, (float*)dst);
+    else relu_pool_kernel<bf16_t><<<g, 256, 0, st>>>(B, Ho, Wo, C, pool, (const bf16_t*)src, (bf16_t*)dst);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_relu_pool_backward(int dtype, int B, int Ho, int Wo, int C, int pool, const void* src, const void* dy, const void* add,
+                                     void* dx, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && Ho > 0 && Wo > 0 && C > 0 && (pool == 1 || pool == 2) && src && dy && dx);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid((long)B * Ho * Wo * C);
+    if (dtype == SR_F32)
+        relu_pool_bwd_kernel<float><<<g, 256, 0, st>>>(B, Ho, Wo, C, pool, (const float*)src, (const float*)dy, (const float*)add, (float*)dx);
+    else
+        relu_pool_bwd_kernel<bf16_t><<<g, 256, 0, st>>>(B, Ho, Wo, C, pool, (const bf16_t*)src, (const bf16_t*)dy, (const bf16_t*)add, (bf16_t*)dx);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_l1_feature_loss(int dtype, long n, const void* a, const void* b, float weight, float* loss, void* grad_a, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && n > 0 && a && b && loss);
+    hipStream_t st = (hipStream_t)stream;
+    int g = head_grid(n);
+    if (g > 1024) g = 1024;
+    if (dtype == SR_F32) l1_feature_kernel<float><<<g, 256, 0, st>>>(n, (const float*)a, (const float*)b, weight, loss, (float*)grad_a);
+    else l1_feature_kernel<bf16_t><<<g, 256, 0, st>>>(n, (const bf16_t*)a, (const bf16_t*)b, weight, loss, (bf16_t*)grad_a);
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_vgg_prep(int dtype, int B, int Cs, int H, int W, const float* src, void* dst, const float* mean3, const float* std3,
+                           int adjoint, void* stream) {
+    SR_REQUIRE(dtype_ok(dtype) && B > 0 && (Cs == 1 || Cs == 3) && H > 0 && W > 0 && src && dst);
+    SR_REQUIRE((mean3 == nullptr) == (std3 == nullptr));
+    hipStream_t st = (hipStream_t)stream;
+    const long npix = (long)H * W;
+    const int g = head_grid((long)B * npix);
+    const int norm = mean3 != nullptr;
+    const float m0 = norm ? mean3[0] : 0.f, m1 = norm ? mean3[1] : 0.f, m2 = norm ? mean3[2] : 0.f;
+    const float s0 = norm ? std3[0] : 1.f, s1 = norm ? std3[1] : 1.f, s2 = norm ? std3[2] : 1.f;
+    if (!adjoint) {  // src: float image (B,Cs,H,W) -> dst: (B,H,W,3) in dtype
+        if (dtype == SR_F32) vgg_prep_kernel<float><<<g, 256, 0, st>>>(B, Cs, npix, src, (float*)dst, m0, m1, m2, s0, s1, s2, norm);
+        else vgg_prep_kernel<bf16_t><<<g, 256, 0, st>>>(B, Cs, npix, src, (bf16_t*)dst, m0, m1, m2, s0, s1, s2, norm);
+    } else {         // dst: gradient (B,H,W,3) in dtype -> src (written): float gradient (B,Cs,H,W)
+        if (dtype == SR_F32) vgg_prep_bwd_kernel<float><<<g, 256, 0, st>>>(B, Cs, npix, (const float*)dst, const_cast<float*>(src), s0, s1, s2, norm);
+        else vgg_prep_bwd_kernel<bf16_t><<<g, 256, 0, st>>>(B, Cs, npix, (const bf16_t*)dst, const_cast<float*>(src), s0, s1, s2, norm);
+    }
+    SR_LAUNCH_CHECK();
+    return SR_OK;
+}
+
+extern "C" int sr_bilinear_resize_backward(const float* ddst, float* dsrc, long planes, int Hs, int Ws, int Hd, int Wd, void* stream) {
+    SR_REQUIRE(ddst && dsrc && planes > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0);
+    hipStream_t st = (hipStream_t)stream;
+    SR_HIP(hipMemsetAsync(dsrc, 0, (size_t)planes * Hs * Ws * sizeof(float), st));
+    bilinear_resize_bwd_kernel<<<head_grid(planes * Hd * Wd), 256, 0, st>>>(ddst, dsrc, planes, Hs, Ws, Hd, Wd);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

@@ -343,6 +343,40 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(View dy, long npix, long
     }
 }
 
+// bf16, 8 | cout <= 256: cout / 8 lanes per pixel (16 bytes each), 256 / (cout / 8) pixels per iteration of the workgroup,
+// several iterations in flight; per-thread sums meet in LDS and leave as `cout` atomics per workgroup
+__global__ __launch_bounds__(256) void bias_grad_vec_kernel(View dy, long npix, long total_pix, int cout, float* __restrict__ dbias,
+                                                            int pix_per_block) {
+    __shared__ float sh[256][9];
+    const int tpp = cout >> 3;            // threads per pixel
+    const int slots = 256 / tpp;          // pixels per iteration
+    const int sub = threadIdx.x % tpp, slot = threadIdx.x / tpp;
+    const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(total_pix, p0 + pix_per_block);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (slot < slots) {
+#pragma unroll 4
+        for (long p = p0 + slot; p < p1; p += slots) {
+            const int b = (int)(p / npix);
+            const uint4 q = *(const uint4*)((const bf16_t*)dy.p + voff(dy, b, p - (long)b * npix, sub * 8));
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] += lo_f(w[i]);
+                acc[2 * i + 1] += hi_f(w[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    if ((int)threadIdx.x < cout) {
+        const int s = threadIdx.x >> 3, i = threadIdx.x & 7;
+        float tot = 0.f;
+        for (int k = 0; k < slots; ++k) tot += sh[k * tpp + s][i];
+        atomicAdd(dbias + threadIdx.x, tot);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // FBM backward: one wavefront per pixel, lanes over channels
 __device__ __forceinline__ float wsum(float v) {
@@ -813,8 +847,12 @@ extern "C" int sr_conv3x3_wgrad(int dtype, int B, int H, int W, const sr_concat*
     if (dbias) {
         SR_HIP(hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), st));
         const long total = (long)B * npix;
-        const int ppb = 256;
-        if (dtype == SR_F32)
+        int ppb = 256;
+        if (dtype == SR_BF16 && cout % 8 == 0 && cout <= 256 && 256 % (cout / 8) == 0 && wm_view_ok(dyv)) {
+            // every workgroup ends in `cout` atomics on the same addresses: ~256 workgroups of long, vectorised runs
+            while (ppb < 8192 && total / ppb > 256) ppb *= 2;
+            bias_grad_vec_kernel<<<cdiv(total, ppb), 256, 0, st>>>(dyv, npix, total, cout, dbias, ppb);
+        } else if (dtype == SR_F32)
             bias_grad_kernel<float><<<cdiv(total, ppb), 256, 0, st>>>(dyv, npix, total, cout, dbias, ppb);
         else
             bias_grad_kernel<bf16_t><<<cdiv(total, ppb), 256, 0, st>>>(dyv, npix, total, cout, dbias, ppb);

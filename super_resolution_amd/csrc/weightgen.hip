@@ -112,7 +112,7 @@ __host__ __device__ inline int mods_stride(int cin, int cout) { return (2 * cin 
 
 template <bool TRAIN>
 __global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp, int Btot,
-                                                   int bpb, float momentum, float* __restrict__ mods) {
+                                                   int bpb, float momentum, float* __restrict__ mods, int staged) {
     extern __shared__ float sh[];
     const int cin = lp.cin, cout = lp.cout;
     const int ms = mods_stride(cin, cout);
@@ -127,11 +127,20 @@ __global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ poo
     float* mean = z + B * ATT;     // [ATT]
     float* var = mean + ATT;       // [ATT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    // staged (train mode, one workgroup for the batch on an otherwise idle chip): pooled means and fc weights through LDS --
+    // the loop below is otherwise a chain of B * 16 / 16 global round trips per wavefront (40 us per layer)
+    float* ps = var + ATT;       // [B][cin]
+    float* fw = ps + B * cin;    // [ATT][cin]
+    if (staged) {
+        for (int i = tid; i < B * cin; i += blockDim.x) ps[i] = pooled[(long)(i / cin) * pooled_ld + i % cin];
+        for (int i = tid; i < ATT * cin; i += blockDim.x) fw[i] = lp.fc_w[i];
+        __syncthreads();
+    }
     // fc (no bias): one wavefront reduction per (sample, attention channel)
     for (int pair = wave; pair < B * ATT; pair += nw) {
         const int b = pair / ATT, k = pair - b * ATT;
-        const float* g = pooled + (long)b * pooled_ld;
-        const float* w = lp.fc_w + (long)k * cin;
+        const float* g = staged ? ps + (long)b * cin : pooled + (long)b * pooled_ld;
+        const float* w = staged ? fw + (long)k * cin : lp.fc_w + (long)k * cin;
         float s = 0.f;
         for (int i = lane; i < cin; i += 64) s += w[i] * g[i];
         s = wave_sum(s);
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ poo
     }
     // KSM_Local: LayerNorm over the channel axis (biased variance, eps 1e-5), one wavefront per sample
     for (int b = wave; b < B; b += nw) {
-        const float* g = pooled + (long)b * pooled_ld;
+        const float* g = staged ? ps + (long)b * cin : pooled + (long)b * pooled_ld;
         float s = 0.f;
         for (int i = lane; i < cin; i += 64) s += g[i];
         const float m = wave_sum(s) / cin;
@@ -249,11 +258,14 @@ int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const
     if (lp.loc_taps > 15) return SR_ERR_ARG;
     if (train && (B < 2 || B > KSM_MAX_B)) return SR_ERR_ARG;  // BatchNorm needs more than one value per channel
     if (train) {
-        const size_t sh = ((size_t)B * ATT + 2 * ATT) * sizeof(float);
-        ksm_kernel<true><<<1, B >= 4 ? 1024 : 256, sh, st>>>(pooled, pooled_ld, lp, B, B, momentum, mods);
+        size_t sh = ((size_t)B * ATT + 2 * ATT) * sizeof(float);
+        const size_t sh_staged = sh + ((size_t)B * lp.cin + (size_t)ATT * lp.cin) * sizeof(float);
+        const int staged = sh_staged <= 60 * 1024;
+        if (staged) sh = sh_staged;
+        ksm_kernel<true><<<1, B >= 4 ? 1024 : 256, sh, st>>>(pooled, pooled_ld, lp, B, B, momentum, mods, staged);
     } else {
         const size_t sh = (3 * ATT) * sizeof(float);
-        ksm_kernel<false><<<B, 256, sh, st>>>(pooled, pooled_ld, lp, B, 1, momentum, mods);
+        ksm_kernel<false><<<B, 256, sh, st>>>(pooled, pooled_ld, lp, B, 1, momentum, mods, 0);
     }
     SR_LAUNCH_CHECK();
     dim3 grid(cdiv((long)lp.cout * lp.cin, 256), B);

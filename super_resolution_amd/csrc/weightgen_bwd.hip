@@ -299,10 +299,10 @@ __global__ __launch_bounds__(256) void wp_ln(const float* __restrict__ G, const 
 // KSM_Global backward, one workgroup for the whole batch (BatchNorm couples the samples in train mode).
 // dpre: global scratch [B][per] for the pre-sigmoid gradients of the four heads (recomputing them inside the two loops that
 // use them cost 3 dependent loads per term: 129 us per layer)
-template <bool TRAIN>
+template <bool TRAIN, bool STAGED>
 __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pooled, int pooled_ld, sr_layer_params lp, int B,
                                                   const float* __restrict__ mods, const float* __restrict__ dca,
-                                                  const float* __restrict__ dfa, const float* __restrict__ dsk, float* __restrict__ dpre,
+                                                  const float* __restrict__ dfa, const float* __restrict__ dsk, float* __restrict__ dpre_g,
                                                   WpGrads g, float* __restrict__ dpooled, int dpooled_ld) {
     extern __shared__ float sh[];
     const int cin = lp.cin, cout = lp.cout, ms = wp_mods_stride(cin, cout);
@@ -313,6 +313,29 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
     float* stat = dz + B * WATT;    // mean[16] | rstd[16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
     const int per = cin + cout + 9 + WKN;
+    // STAGED: the pooled means, the fc weights, the four heads' weights and the pre-sigmoid gradients live in LDS.  This is
+    // ONE workgroup on an otherwise idle chip: every global access is a full memory round trip, and the loops below are
+    // chains of them (125 us per layer with everything read from global memory where it lies).
+    float* ps = stat + 64;                         // [B][cin]
+    float* fw = ps + (STAGED ? B * cin : 0);       // [ATT][cin]
+    float* hw = fw + (STAGED ? WATT * cin : 0);    // [per][ATT]: channel_fc | filter_fc | spatial_fc | kernel_fc rows
+    float* dpre = STAGED ? hw + per * WATT : dpre_g;  // [B][per]
+    const float* pp = STAGED ? ps : pooled;
+    const int pld = STAGED ? cin : pooled_ld;
+    const float* fcw = STAGED ? fw : lp.fc_w;
+    if (STAGED) {
+        for (int i = tid; i < B * cin; i += nt) ps[i] = pooled[(long)(i / cin) * pooled_ld + i % cin];
+        for (int i = tid; i < WATT * cin; i += nt) fw[i] = lp.fc_w[i];
+        for (int i = tid; i < per * WATT; i += nt) {
+            const int j = i / WATT;
+            float v;
+            if (j < cin) v = lp.ch_w[i];
+            else if (j < cin + cout) v = lp.fl_w[i - cin * WATT];
+            else if (j < cin + cout + 9) v = lp.sp_w[i - (cin + cout) * WATT];
+            else v = lp.kn_w[i - (cin + cout + 9) * WATT];
+            hw[i] = v;
+        }
+    }
     // pre-sigmoid gradients:  ca, fa, sa = 2 sigmoid(v): d/dv = y (1 - y/2);  ka = 2/KN sigmoid(v): d/dv = y (1 - y KN / 2)
     for (int it = tid; it < B * per; it += nt) {
         const int b = it / per, j = it - b * per;
@@ -324,16 +347,17 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
         else { const int r = j - cin - cout - 9; const float y = md[2 * cin + cout + 9 + r]; v = dsk[(long)b * 16 + 9 + r] * y * (1.0f - 0.5f * WKN * y); }
         dpre[it] = v;
     }
+    __threadfence_block();
+    __syncthreads();
     for (int pair = wave; pair < B * WATT; pair += nw) {
         const int b = pair / WATT, k = pair - b * WATT;
-        const float* p = pooled + (long)b * pooled_ld;
-        const float* w = lp.fc_w + (long)k * cin;
+        const float* p = pp + (long)b * pld;
+        const float* w = fcw + (long)k * cin;
         float s = 0.f;
         for (int i = lane; i < cin; i += 64) s += w[i] * p[i];
         s = wp_wave_sum(s);
         if (lane == 0) zh[pair] = s;
     }
-    __threadfence_block();
     __syncthreads();
     if (tid < WATT) {
         float m, var;
@@ -374,11 +398,16 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
         const int b = pair / WATT, k = pair - b * WATT;
         float s = 0.f;
         for (int j = lane; j < per; j += 64) {
-            const float* w;
-            float *gw, *gb;
-            int row;
-            head(j, w, gw, gb, row);
-            s += dpre[(long)b * per + j] * w[row * WATT + k];
+            float wv;
+            if (STAGED) wv = hw[j * WATT + k];
+            else {
+                const float* w;
+                float *gw, *gb;
+                int row;
+                head(j, w, gw, gb, row);
+                wv = w[row * WATT + k];
+            }
+            s += dpre[(long)b * per + j] * wv;
         }
         s = wp_wave_sum(s);
         if (lane == 0) dz[pair] = s;
@@ -435,14 +464,14 @@ __global__ __launch_bounds__(1024) void wp_global(const float* __restrict__ pool
     for (int i = tid; i < WATT * cin; i += nt) {
         const int k = i / cin, c = i - k * cin;
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dz[b * WATT + k] * pooled[(long)b * pooled_ld + c];
+        for (int b = 0; b < B; ++b) s += dz[b * WATT + k] * pp[(long)b * pld + c];
         g.fc_w[i] = s;
     }
     for (int i = tid; i < B * cin; i += nt) {
         const int b = i / cin, c = i - b * cin;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < WATT; ++k) s += dz[b * WATT + k] * lp.fc_w[k * cin + c];
+        for (int k = 0; k < WATT; ++k) s += dz[b * WATT + k] * fcw[k * cin + c];
         dpooled[(long)b * dpooled_ld + c] += s;  // the local (LayerNorm) part was written by wp_ln
     }
 }
@@ -511,9 +540,14 @@ extern "C" int sr_fdconv_weightgen_backward(int B, const float* pooled, int pool
     const int N1 = 3 * cout, N2 = 3 * cin, n2h = N2 / 2 + 1;
     // S and the reductions are adjacent: one memset (l.red follows l.S up to alignment padding)
     SR_HIP(hipMemsetAsync(S, 0, (l.red - l.S) + l.red_floats * 4, st));
-    SR_HIP(hipMemsetAsync(g.loc_w, 0, (size_t)cout * 9 * taps * 4, st));
-    SR_HIP(hipMemsetAsync(g.ln_w, 0, (size_t)cin * 4, st));
-    SR_HIP(hipMemsetAsync(g.ln_b, 0, (size_t)cin * 4, st));
+    const size_t n_locw = (size_t)cout * 9 * taps;
+    if (g.ln_w == g.loc_w + n_locw && g.ln_b == g.ln_w + cin) {  // one flat gradient buffer (the Python host's): one memset
+        SR_HIP(hipMemsetAsync(g.loc_w, 0, (n_locw + 2 * (size_t)cin) * 4, st));
+    } else {
+        SR_HIP(hipMemsetAsync(g.loc_w, 0, n_locw * 4, st));
+        SR_HIP(hipMemsetAsync(g.ln_w, 0, (size_t)cin * 4, st));
+        SR_HIP(hipMemsetAsync(g.ln_b, 0, (size_t)cin * 4, st));
+    }
     // batch chunks: enough workgroups to fill the chip, as few atomic rounds on S / d loc_w as that allows
     const int wgs = cdiv(cin, 64) * cdiv(cout, 4);
     int nz = (512 + wgs - 1) / wgs;
@@ -536,14 +570,24 @@ extern "C" int sr_fdconv_weightgen_backward(int B, const float* pooled, int pool
     SR_LAUNCH_CHECK();
     wp_ln<<<B, 256, (2 * (size_t)cin + 8) * 4, st>>>(G, pooled, pooled_ld, *lp, dpooled, dpooled_ld, accumulate, g.ln_w, g.ln_b);
     SR_LAUNCH_CHECK();
-    const size_t shg = ((size_t)4 * B * WATT + 64) * 4;
+    const int per = cin + cout + 9 + WKN;
+    const size_t sh_base = ((size_t)4 * B * WATT + 64 + 64) * 4;
+    const size_t sh_staged = sh_base + ((size_t)B * cin + (size_t)WATT * cin + (size_t)per * WATT + (size_t)B * per) * 4;
+    const bool staged = sh_staged <= 150 * 1024;
+    const size_t shg = staged ? sh_staged : sh_base;
+#define SR_WPG(TR_, ST_)                                                                                                            \
+    do {                                                                                                                            \
+        SR_LDS_ATTR(shg, wp_global<TR_, ST_>);                                                                                      \
+        wp_global<TR_, ST_><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsk, dpre, g, dpooled, dpooled_ld);     \
+    } while (0)
     if (train) {
-        SR_LDS_ATTR(shg, wp_global<true>);
-        wp_global<true><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsk, dpre, g, dpooled, dpooled_ld);
+        if (staged) SR_WPG(true, true);
+        else SR_WPG(true, false);
     } else {
-        SR_LDS_ATTR(shg, wp_global<false>);
-        wp_global<false><<<1, 1024, shg, st>>>(pooled, pooled_ld, *lp, B, mods, dca, dfa, dsk, dpre, g, dpooled, dpooled_ld);
+        if (staged) SR_WPG(false, true);
+        else SR_WPG(false, false);
     }
+#undef SR_WPG
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

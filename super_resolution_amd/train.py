@@ -46,11 +46,12 @@ _WP_FIELDS = (('dft_weight', 'dft_weight'), ('fc_w', 'KSM_Global.fc.weight'), ('
 assert tuple(f for f, _ in _WP_FIELDS) == L.WEIGHT_PATH_GRADS
 
 
-def weight_path_backward(m, lp, pooled, pooled_ld, mods, dw, training, dpooled=None, dpooled_ld=None):
+def weight_path_backward(m, lp, pooled, pooled_ld, mods, dw, training, dpooled=None, dpooled_ld=None, accumulate=False):
     """dW_b (B, 9, Cout, Cin) float32 -> ({parameter name: gradient}, dpooled (B, Cin)) for the weight path of FDConv `m`
     (KSM_Global, KSM_Local, spectrum), one call into libsr_amd (`sr_fdconv_weightgen_backward`: hand-written kernels, no
     torch operator).  `mods` is the workspace the forward's sr_fdconv_weightgen left behind; `pooled` may be a wider
-    buffer (pooled_ld floats per sample).  dpooled: optional destination (B rows of dpooled_ld floats), else allocated."""
+    buffer (pooled_ld floats per sample).  dpooled: optional destination (tensor or device address, B rows of dpooled_ld floats;
+    accumulate: added to instead of overwritten), else allocated."""
     lib, dev = L.lib(), dw.device
     B = dw.shape[0]
     cin, cout = m.in_channels, m.out_channels
@@ -74,8 +75,8 @@ def weight_path_backward(m, lp, pooled, pooled_ld, mods, dw, training, dpooled=N
     ws = torch.empty(lib.sr_fdconv_weightgen_backward_workspace_bytes(B, cin, cout), dtype=torch.uint8, device=dev)
     L.check(lib.sr_fdconv_weightgen_backward(B, pooled.data_ptr(), pooled_ld, C.byref(lp), int(training), mods.data_ptr(),
                                              m.dft_weight.data_ptr(), m.group_map().data_ptr(), float(m.alpha), dw.data_ptr(),
-                                             C.byref(gs), dpooled.data_ptr(), dpooled_ld, ws.data_ptr(), ws.numel(),
-                                             L.stream_ptr(dev)), 'sr_fdconv_weightgen_backward')
+                                             C.byref(gs), dpooled.data_ptr() if torch.is_tensor(dpooled) else dpooled, dpooled_ld,
+                                             int(accumulate), ws.data_ptr(), ws.numel(), L.stream_ptr(dev)), 'sr_fdconv_weightgen_backward')
     return out, dpooled
 
 
@@ -342,7 +343,8 @@ class _Group:
         if bands:
             self.l2, self.l4, self.l8 = (torch.empty_like(self.x) for _ in range(3))
             self.pooled = torch.empty(B, Cc, dtype=torch.float32, device=dev)
-        self.dx = self.dl2 = self.dl4 = self.dl8 = None
+        self.dx = self.dl2 = self.dl4 = self.dl8 = self.dpool = None
+        self.use_dpool = False
 
     def open_backward(self, covers_all):
         """Called by every consumer in backward; True for the one that must WRITE the accumulators instead of adding to
@@ -354,6 +356,7 @@ class _Group:
         self.dx = make(self.x)
         if self.has_bands:
             self.dl2, self.dl4, self.dl8 = (make(self.x) for _ in range(3))
+            self.dpool = torch.zeros_like(self.pooled)   # summed pooled-mean gradients of the consumers (matrix-core gate path)
         return covers_all
 
 
@@ -397,8 +400,9 @@ class _Runner:
             L.check(lib.sr_fbm_lowpass(plan, self.code, B, src, 0, planes[0], planes[1], planes[2], None, 0, ws.data_ptr(), ws.numel(),
                                        self.st), 'sr_fbm_lowpass (adjoint)')
 
-    def combine(self, B, H, W, Cc, terms, scales, act=None, slope=1.0, out=None):
-        """out = mask(act) * sum_j scales[j] * terms[j]; terms / act / out are sr_views; returns the output tensor."""
+    def combine(self, B, H, W, Cc, terms, scales, act=None, slope=1.0, out=None, bc=None, bc_ld=0, bc_scale=0.0):
+        """out = mask(act) * (sum_j scales[j] * terms[j] + bc_scale * bc[b][c]); terms / act / out are sr_views, bc a device
+        address of (B, bc_ld) floats or None; returns the output tensor."""
         res = None
         if out is None:
             res = torch.empty(B, H, W, Cc, dtype=self.dt, device=self.dev)
@@ -406,7 +410,7 @@ class _Runner:
         tv = (L.View * len(terms))(*terms)
         sv = (C.c_float * len(terms))(*scales)
         L.check(self.lib.sr_grad_combine(self.code, B, H, W, Cc, len(terms), tv, sv, act if act is not None else L.View(), float(slope),
-                                         out, self.st), 'sr_grad_combine')
+                                         bc, bc_ld, float(bc_scale), out, self.st), 'sr_grad_combine')
         return res
 
     def resample(self, src, adjoint):
@@ -528,11 +532,17 @@ class _Runner:
         L.check(lib.sr_fbm_backward(self.code, B, H, W, xv, cc.l2[0], cc.l4[0], cc.l8[0], gates.data_ptr(), L.view(da), dxv,
                                     L.view(grp.dl2, cin, 0), L.view(grp.dl4, cin, 0), L.view(grp.dl8, cin, 0), dz.data_ptr(),
                                     0 if first else 1, L.ptr(dzp), st), 'sr_fbm_backward')
-        # 4. the weight path: dW_b -> parameters and pooled means
-        wgrads, dpooled = weight_path_backward(m, lp, grp.pooled, grp.C, rec['mods'], dw, self.training)
+        # 4. the weight path: dW_b -> parameters and pooled means.  Matrix-core gate path: the pooled-mean gradients of all
+        # consumers are summed in the group's (B, C) buffer and enter once per slice (slice_grad); else per layer (step 5)
+        if mfma_gates:
+            grp.use_dpool = True
+            wgrads, dpooled = weight_path_backward(m, lp, grp.pooled, grp.C, rec['mods'], dw, self.training, dpooled=grp.dpool,
+                                                   dpooled_ld=grp.C, accumulate=True)
+        else:
+            wgrads, dpooled = weight_path_backward(m, lp, grp.pooled, grp.C, rec['mods'], dw, self.training)
         for name, gten in wgrads.items():
             grads[params[name]] = gten
-        # 5. gate convs: weight gradients, and their input gradient + the pooled-mean term added to the direct branch
+        # 5. gate convs: weight gradients, and their input gradient added to the direct branch
         if mfma_gates:
             dw32 = torch.empty(9, 32, cin, dtype=torch.float32, device=dev)
             db32 = torch.empty(32, dtype=torch.float32, device=dev)
@@ -544,16 +554,22 @@ class _Runner:
             # (9, cin) slices of dw32 viewed as (1, cin, 3, 3): no copy (the optimizer's flatten reads them as they lie)
             gate_w = [dw32[:, k, :].t().unsqueeze(0).view(1, cin, 3, 3) for k in range(3)]
             gate_b = [db32[k:k + 1] for k in range(3)]
-            gw_ptr = gb_ptr = None
+            # input gradient of the three gate convs: ONE 32 -> cin convolution of the padded logit gradients on the matrix
+            # cores, the direct branch as its residual operand (the VALU kernel took 200 us per 192-channel layer)
+            gwt = torch.empty(2, 9, cin, 32, dtype=torch.bfloat16, device=dev)
+            L.check(lib.sr_pack_gate_weight_transposed(C.byref(lp), gwt[0].data_ptr(), gwt[1].data_ptr(), st), 'sr_pack_gate_weight_transposed')
+            ep = L.Epilogue()
+            ep.r1, ep.s1 = dxv, 1.0
+            L.check(lib.sr_conv3x3(self.code, B, H, W, C.byref(_concat1(dzp)), None, gwt.data_ptr(), 0, 9 * cin * 32, cin, C.byref(ep), dxv, st),
+                    'sr_conv3x3 (transposed gate convs)')
         else:
             dgw = torch.empty(3, cin, 9, dtype=torch.float32, device=dev)
             dgb = torch.empty(3, dtype=torch.float32, device=dev)
-            gw_ptr, gb_ptr = dgw.data_ptr(), dgb.data_ptr()
             gate_w = [dgw[k].reshape(1, cin, 3, 3) for k in range(3)]
             gate_b = [dgb[k:k + 1] for k in range(3)]
-        nv = L.View()
-        L.check(lib.sr_fbm_gates_backward(self.code, B, H, W, xv, dz.data_ptr(), C.byref(lp), dxv, nv, nv, nv, dpooled.data_ptr(), cin, dxv,
-                                          gw_ptr, gb_ptr, st), 'sr_fbm_gates_backward')
+            nv = L.View()
+            L.check(lib.sr_fbm_gates_backward(self.code, B, H, W, xv, dz.data_ptr(), C.byref(lp), dxv, nv, nv, nv, dpooled.data_ptr(), cin, dxv,
+                                              dgw.data_ptr(), dgb.data_ptr(), st), 'sr_fbm_gates_backward')
         for k in range(3):
             grads[params['FBM.freq_weight_conv_list.%d.weight' % k]] = gate_w[k]
             grads[params['FBM.freq_weight_conv_list.%d.bias' % k]] = gate_b[k]
@@ -574,6 +590,9 @@ class _Runner:
         for v, sc in extras:
             terms.append(v)
             scales.append(sc)
+        if grp.use_dpool:  # summed pooled-mean gradients of the slice's consumers: + dpool[b][c] / (H W) at every pixel
+            return self.combine(B, H, W, Cc, terms, scales, act=act, slope=slope, bc=grp.dpool.data_ptr() + 4 * c0, bc_ld=grp.C,
+                                bc_scale=1.0 / (H * W))
         return self.combine(B, H, W, Cc, terms, scales, act=act, slope=slope)
 
     # ---- the network --------------------------------------------------------------------------------------------
@@ -933,16 +952,22 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps = steps
 
 
-def train_step(net, optimizer, wf, sr, weighted=False, sigmoid=False, clip_grad_norm=None, group=None):
+def train_step(net, optimizer, wf, sr, weighted=False, sigmoid=False, clip_grad_norm=None, group=None, perceptual=None):
     """One optimisation step shaped as train/train_realESRGAN_fdconv_1.py:113-118 (weighted / sigmoid / clip: the variants of
     train/train_realESRGAN_fdconv.py:107-142): forward, bilinear resize to the target size + L1 (one fused HIP kernel that
     also returns d loss / d pred), backward, gradient all-reduce when torch.distributed is initialised, optimizer step.
+    perceptual: None, or a dict(vgg=VGG19Features, layer_weights=..., weight=1.0, compute_dtype=...) -- adds the VGG-feature
+    L1 term of the Real-ESRGAN recipe (options/train_realesrgan_x4plus.yml:129-149: L1 + perceptual, BASELINE configs[3]).
     Returns the loss (a 0-d device tensor)."""
     from .head import resize_l1_loss
     net.train()
     optimizer.zero_grad()
     pred = net(wf)
     loss = resize_l1_loss(pred, sr, weighted=weighted, sigmoid=sigmoid)
+    if perceptual is not None:
+        from .perceptual import perceptual_loss
+        loss = loss + perceptual_loss(pred, sr, perceptual['vgg'], perceptual.get('layer_weights'), perceptual.get('weight', 1.0),
+                                      perceptual.get('compute_dtype', torch.bfloat16))
     loss.backward()
     if isinstance(optimizer, FlatAdam):  # gathers, all-reduces and clips the flat gradient itself
         optimizer.step(group=group, clip_grad_norm=clip_grad_norm)
