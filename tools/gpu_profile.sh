@@ -13,14 +13,14 @@ cd /tmp
 echo "[gpu_profile] bench"
 timeout -k 10 300 python3 "$R/bench.py" --steps 5 --warmup 2 "$@" > "$O/bench.json" 2> "$O/bench.err"
 echo "[gpu_profile] kernel trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$O/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary "$@" > "$O/trace.log" 2>&1
 python3 "$R/tools/prof_summary.py" "$O/trace" > "$O/kernel_summary.txt"
 S=$(find "$O/trace" -name '*kernel_stats.csv' | head -n 1)
 [ -n "$S" ] && cp "$S" "$O/kernel_stats.csv"
 echo "[gpu_profile] pmc FETCH_SIZE"
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$O/pmc_fetch.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-secondary "$@" > "$O/pmc_fetch.log" 2>&1
 echo "[gpu_profile] pmc WRITE_SIZE"
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$O/pmc_write.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-secondary "$@" > "$O/pmc_write.log" 2>&1
 python3 "$R/tools/hbm_traffic.py" "$O/pmc_fetch" "$O/pmc_write" "$O/hbm_traffic.json" > /dev/null
 # the raw traces are large: keep the summaries only
 rm -rf "$O/trace" "$O/pmc_fetch" "$O/pmc_write"
