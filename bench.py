@@ -510,9 +510,13 @@ def main():
     if world > 1:
         dist.barrier()
 
+    for spec in filter(None, os.environ.get('SR_BENCH_DEBUG_HOOKS', '').split(',')):  # A/B runs: "sr_debug_xxx=1,sr_debug_yyy=0"
+        from super_resolution_amd import _lib
+        name, _, val = spec.partition('=')
+        getattr(_lib.lib(), name.strip())(int(val or '1'))
     if os.environ.get('SR_BENCH_SPLIT_TWO_PASS'):
         from super_resolution_amd import _lib
-        _lib.lib().sr_debug_split_two_pass(1)
+        _lib.lib().sr_debug_split_two_pass(int(os.environ['SR_BENCH_SPLIT_TWO_PASS']))
     if args.no_split_weights:
         from super_resolution_amd import _lib
         _lib.lib().sr_debug_split_weights(0)

@@ -210,7 +210,12 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
 //   SPLIT 0, 2: loaders  pixels(s) -> barrier_s                          MFMA waves  barrier_s -> DMA slabs(s+1) -> multiply(s)
 //   SPLIT 1   : loaders  pixels(s) first half -> barrier'_{s-1} -> second half -> barrier_s  (+ one barrier after the last chunk)
 //               MFMA waves  barrier_s -> multiply(s) -> barrier'_s -> DMA slabs(s+1)
-template <int MT, bool BANDS, int SPLIT>
+// RES (shared weights, SPLIT = 0, one output block): the slabs of EVERY chunk of the layer stay in LDS for the whole kernel
+// (a plain 64 -> 64 layer is 73.7 KB, as much as the double-buffered slabs of the streaming form): they are fetched once
+// per workgroup instead of once per tile and chunk -- for a plain layer the slab is as many bytes as the chunk's pixels --
+// and no chunk barrier has to drain the MFMA waves' vector-memory counter any more, so the epilogue's stores retire
+// behind the next tile's multiplies.
+template <int MT, bool BANDS, int SPLIT, bool RES = false>
 __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, long w_lo_off,
                                                          int cin, int cout, Epilogue ep, View out, unsigned total, int wmap) {
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         return;
     }
     unsigned step = 0;
-    float* bias_lds = (float*)(lds + 2 * STAGE_PX + (SPLIT == 2 ? 4 : 2) * WSLAB);  // [cout], zeros without a bias
+    float* bias_lds = (float*)(lds + 2 * STAGE_PX + (RES ? nchunks : (SPLIT == 2 ? 4 : 2)) * WSLAB);  // [cout], zeros without a bias
     float* slope_lds = bias_lds + cout;  // [cout] negative slopes: PReLU's, 0.2 for LeakyReLU, 1 without activation
     for (int i = tid; i < cout; i += 256) {
         bias_lds[i] = ep.bias ? ep.bias[i] : 0.f;
@@ -441,7 +446,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             }
         }
     };
-    {  // slabs of the workgroup's very first chunk
+    if (RES) {  // every chunk's slab, once (shared weights: sample 0, output block 0)
+        for (int c = 0; c < nchunks; ++c) slab_dma(0, 0, c * 32, 0, lds_wa + c * WSLAB);
+    } else {  // slabs of the workgroup's very first chunk
         const TileId t0 = decode_tile<MT>(walk.next, tiles, tilesx, B);
         if (SPLIT == 2) {
             slab_dma(t0.b, t0.o_blk, 0, 0, lds_wa);
@@ -526,8 +533,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 no = tn.o_blk;
             }
             const int nkc = last_c ? 0 : (c + 1) * 32;
-            __syncthreads();  // chunk `step`: pixel stage in place (loaders), own slab DMA drained (vmcnt), previous chunk consumed
-            if (SPLIT == 1) {
+            if (RES && step) lds_barrier();  // resident slabs: nothing of this wave's vector memory traffic is waited for
+            else __syncthreads();  // chunk `step`: pixel stage in place (loaders), own slab DMA drained (vmcnt), previous chunk consumed
+            if (RES) {
+                multiply(cur_px, lds_wa + c * WSLAB, nullptr);
+            } else if (SPLIT == 1) {
                 // one slab pair [hi][lo] (four slabs of 36 KB do not fit next to the two pixel stages at MT = 2): the next
                 // chunk's slabs can only be requested once every MFMA wave has finished this chunk -- second barrier
                 multiply(cur_px, lds_wa, lds_wb);
@@ -671,23 +681,26 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
     return true;
 }
 
-template <int MT, bool BANDS, int SPLIT>
+template <int MT, bool BANDS, int SPLIT, bool RES = false>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
-    const size_t ldsb = 2 * (size_t)NPIX * 64 + (SPLIT == 2 ? 4 : 2) * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
+    const size_t nslab = RES ? (size_t)(in.ctot / 32) : (SPLIT == 2 ? 4 : 2);
+    const size_t ldsb = 2 * (size_t)NPIX * 64 + nslab * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
-    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT>);  // per device
+    if (RES && (wbs != 0 || wlo != 0 || cdiv(cout, MT * 32) != 1)) return SR_NOT_ELIGIBLE;
+    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT, RES>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
     if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-    conv3x3_mfma_bf16<MT, BANDS, SPLIT><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk, g_split_two_pass);
+    conv3x3_mfma_bf16<MT, BANDS, SPLIT, RES><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk, g_split_two_pass);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
 
 int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
+int g_no_resident = 0;    // test hook (A/B): shared weights streamed per chunk like per-sample ones
 
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
                    long wlo, int cout, const Epilogue& ep, View out, hipStream_t st) {
@@ -702,7 +715,14 @@ int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float
             else rc = two ? SR_MFMA(2, true, 0) : SR_MFMA(1, true, 0);
         } else {
             if (wlo) rc = two ? SR_MFMA(2, false, 1) : SR_MFMA(1, false, 2);
-            else rc = two ? SR_MFMA(2, false, 0) : SR_MFMA(1, false, 0);
+            else {
+                // shared single-part weights that fit LDS whole (e.g. 64 -> 64: 73.7 KB): resident slabs
+                rc = SR_NOT_ELIGIBLE;
+                if (wbs == 0 && !g_no_resident)
+                    rc = two ? launch_mfma<2, false, 0, true>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
+                             : launch_mfma<1, false, 0, true>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
+                if (rc == SR_NOT_ELIGIBLE) rc = two ? SR_MFMA(2, false, 0) : SR_MFMA(1, false, 0);
+            }
         }
 #undef SR_MFMA
         // a layer whose bias / slope tables push the LDS image past 160 KiB (very wide cout) is not an error: VALU kernel
@@ -737,3 +757,6 @@ extern "C" int sr_conv3x3(int dtype, int B, int H, int W, const sr_concat* in, c
 extern "C" void sr_debug_force_generic_conv(int on) { sr::g_force_generic = on; }
 
 extern "C" void sr_debug_split_two_pass(int on) { sr::g_split_two_pass = on; }
+
+// test hook (A/B): 1 = never keep shared weights resident in LDS
+extern "C" void sr_debug_no_resident_weights(int on) { sr::g_no_resident = on; }

@@ -131,3 +131,29 @@ def test_srvgg_bf16_with_a_feature_width_that_is_not_a_multiple_of_32():
         ref = srvgg_forward(t(gp.srvgg_state(*args, seed=610, act_type='prelu')), x.cpu())
     assert (y.cpu() - ref).abs().max().item() < 1e-4
     assert (yb.cpu() - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
+
+
+def test_resident_weight_conv_is_bit_identical_to_the_streamed_form():
+    """Plain (shared-weight) bf16 layers whose whole weight tensor fits LDS keep it resident for the kernel's lifetime
+    (conv3x3_mfma_bf16<.., RES>); per-sample layers and wide ones stream a slab per chunk.  Same arithmetic in the same
+    order: SRVGGNetCompact (64 -> 64 and the 64 -> 48 tail) and a plain RRDBNet (64 -> 32 ... 128 -> 32 resident, 160 -> 32 and
+    192 -> 64 streamed) must come out bit for bit the same through both."""
+    from super_resolution_amd import SRVGGNetCompact, RRDBNet, _lib
+    lib = _lib.lib()
+    net = SRVGGNetCompact(3, 3, 64, 16, 4, act_type='prelu')
+    net.load_state_dict(t(gp.srvgg_state(3, 3, 64, 16, 4, seed=600, act_type='prelu')), strict=True)
+    net = net.eval().cuda()
+    torch.manual_seed(5)
+    rr = RRDBNet(3, 3, 4, 64, 2, 32).eval().cuda()
+    x = torch.from_numpy(gp.image_input((2, 3, 70, 52), seed=602)).cuda().to(torch.bfloat16)
+    outs = []
+    with torch.no_grad():
+        for off in (0, 1):
+            lib.sr_debug_no_resident_weights(off)
+            try:
+                outs.append((net(x).float(), rr(x).float()))
+            finally:
+                lib.sr_debug_no_resident_weights(0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][1]).all() and outs[0][1].abs().max() > 0
