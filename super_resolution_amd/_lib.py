@@ -135,6 +135,7 @@ _SIGS = {
     'sr_debug_split_weights': (None, [C.c_int]),
     'sr_debug_split_two_pass': (None, [C.c_int]),
     'sr_debug_no_resident_weights': (None, [C.c_int]),
+    'sr_debug_no_plain_kernel': (None, [C.c_int]),
     'sr_debug_graph_replays': (C.c_long, [C.c_void_p]),
     'sr_debug_enable_graphs': (None, [C.c_int]),
     'sr_debug_wgrad_valu': (None, [C.c_int]),

@@ -188,6 +188,10 @@ struct Epilogue {
     View r1, r2;
     float s1, s2;
 };
+
+// conv_plain.hip: shared-weight, band-free bf16 layers whose weights fit LDS (SR_NOT_ELIGIBLE: conv.hip's kernels take it)
+int conv3x3_plain_launch(int B, int H, int W, const Concat& in, const void* wts, long wbs, long wlo, int cout, const Epilogue& ep,
+                         View out, hipStream_t st);
 inline Epilogue to_epilogue(const sr_epilogue* e, long npix) {
     Epilogue o{};
     if (e) {
