@@ -120,6 +120,10 @@ int sr_version(void);
  * scale 2 -> r=2, scale 1 -> r=4; r=1: none): dst is (B, H/r, W/r, C*r*r), channel c*r*r+dy*r+dx. */
 int sr_pack_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W, int r,
                  void* stream);
+/* The same layout change with the channel count padded to `cpad` (a multiple of 8; zeros beyond C), bf16 destination
+ * (B, H, W, cpad): a 1- or 3-channel image as one 32-channel K-chunk of the MFMA convolution kernels.  Replaces the
+ * implicit NCHW read of the first nn.Conv2d of SRVGGNetCompact (Real-ESRGAN-master/realesrgan/archs/srvgg_arch.py:34, 56-58). */
+int sr_pack_nchw_padded(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, int cpad, void* stream);
 int sr_unpack_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W,
                    void* stream);
 /* nn.Conv2d weight (cout,cin,3,3) f32 -> [9][cout][cin] in `dtype` (what the conv kernels read); dst_lo (may be NULL)

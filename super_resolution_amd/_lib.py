@@ -60,6 +60,7 @@ _SIGS = {
     'sr_last_hip_error': (C.c_int, []),
     'sr_version': (C.c_int, []),
     'sr_pack_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_pack_nchw_padded': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_unpack_nhwc': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_pack_conv_weight': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_fbm_plan_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -126,9 +126,6 @@ __global__ __launch_bounds__(512) void conv3x3_plain_mfma(Concat in, int B, int 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-        struct Frags {
-            short8 a[MT], b[NR];
-        };
         int c = 0;
         for (int s = 0; s < in.nseg; ++s) {
             const View vx = in.x[s];
@@ -158,43 +155,38 @@ __global__ __launch_bounds__(512) void conv3x3_plain_mfma(Concat in, int B, int 
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // 2. own copies landed (and own earlier stores retired)
-                // ---- 3. multiply: 18 k-steps, fully unrolled; the fragments of k-step s + 1 are requested before the MFMAs of
-                // k-step s are issued (two register sets)
+                // ---- 3. multiply, fully unrolled, in six groups (k-step half kk, column tap dx).  A group reads the NR + 2 strip
+                // rows at that column shift ONCE and uses row n + dy for all three row taps: NR + 2 + 3 MT fragment reads per
+                // 3 NR MT MFMAs (11 per 18 at 64 -> 64) instead of NR + MT per NR MT when every tap reads its own rows (15 per
+                // 18) -- LDS bandwidth is what the MFMAs wait for here.  One fragment set: the other wave of the SIMD fills the
+                // read latency at a group's start.
                 const int wc0 = wa[0] + c * WSLAB, wc1 = wa[1] + c * WSLAB;
-                auto load_step = [&](int dy, int dx, int kk, Frags& f) {
-                    const int tap = dy * 3 + dx;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) f.a[m] = *(const short8*)&lds[(kk ? wc1 : wc0) + (tap * (MT * 32) + m * 32) * 64];
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int n = 0; n < NR; ++n) {
-                        const int K = (n + dy) * PPW + dx;
-                        f.b[n] = *(const short8*)&lds[bb[K & 15][kk] + (K >> 4) * 1024];
+                    for (int dx = 0; dx < 3; ++dx) {
+                        short8 fa[3][MT], fb[NR + 2];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) fa[0][m] = *(const short8*)&lds[(kk ? wc1 : wc0) + (dx * (MT * 32) + m * 32) * 64];
+#pragma unroll
+                        for (int R = 0; R < NR + 2; ++R) {
+                            const int K = R * PPW + dx;
+                            fb[R] = *(const short8*)&lds[bb[K & 15][kk] + (K >> 4) * 1024];
+                        }
+#pragma unroll
+                        for (int dy = 1; dy < 3; ++dy)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                fa[dy][m] = *(const short8*)&lds[(kk ? wc1 : wc0) + ((dy * 3 + dx) * (MT * 32) + m * 32) * 64];
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int n = 0; n < NR; ++n)
+#pragma unroll
+                                for (int m = 0; m < MT; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[dy][m], fb[n + dy], acc[m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);  // groups stay in sequence: unrolled, the scheduler pulls every read up and spills
                     }
-                };
-                auto mfma_step = [&](const Frags& f) {
-#pragma unroll
-                    for (int n = 0; n < NR; ++n)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);  // keep the two-set pipeline as written: unrolled, the scheduler pulls every read up and spills
-                };
-                Frags f0, f1;
-                load_step(0, 0, 0, f0);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    load_step(dy, 0, 1, f1);
-                    mfma_step(f0);
-                    load_step(dy, 1, 0, f0);
-                    mfma_step(f1);
-                    load_step(dy, 1, 1, f1);
-                    mfma_step(f0);
-                    load_step(dy, 2, 0, f0);
-                    mfma_step(f1);
-                    load_step(dy, 2, 1, f1);
-                    mfma_step(f0);
-                    if (dy < 2) load_step(dy + 1, 0, 0, f0);
-                    mfma_step(f1);
-                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read before the strip is overwritten
             }
         }

@@ -77,6 +77,12 @@ class SRVGGNetCompact(nn.Module):
             if cpad != cout:
                 w = torch.cat([w, w.new_zeros(cpad - cout, cin, 3, 3)], 0)
                 b = torch.cat([b, b.new_zeros(cpad - cout)], 0)
+            # bf16 head: the image is packed as ONE 32-channel K-chunk (zeros beyond num_in_ch, sr_pack_nchw_padded) and the
+            # weights are padded to match, so the 3 -> 64 layer runs on the matrix cores like the body (the VALU kernel that
+            # takes thin inputs is bound by its instruction count: 1.17 ms against 0.45 ms for four 1080p frames)
+            if i == 0 and dtype == torch.bfloat16 and cin < 32 and cout % 32 == 0:
+                w = torch.cat([w, w.new_zeros(w.shape[0], 32 - cin, 3, 3)], 1)
+                cin = 32
             wp, lo = L.pack_plain_weight(w.float().contiguous(), dtype, cpad, cin)
             slope = None
             if not last:
@@ -108,8 +114,12 @@ class SRVGGNetCompact(nn.Module):
         with torch.cuda.device(dev):
             st = L.stream_ptr(dev)
             layers = self._layers(dt, dev)
-            cur = torch.empty(B, H, W, Cc, dtype=dt, device=dev)
-            L.check(lib.sr_pack_nchw(x.data_ptr(), io_code, cur.data_ptr(), code, B, Cc, H, W, 1, st), 'sr_pack_nchw')
+            cin0 = layers[0]['cin']
+            cur = torch.empty(B, H, W, cin0, dtype=dt, device=dev)
+            if cin0 != Cc:  # padded bf16 head (see _layers)
+                L.check(lib.sr_pack_nchw_padded(x.data_ptr(), io_code, cur.data_ptr(), B, Cc, H, W, cin0, st), 'sr_pack_nchw_padded')
+            else:
+                L.check(lib.sr_pack_nchw(x.data_ptr(), io_code, cur.data_ptr(), code, B, Cc, H, W, 1, st), 'sr_pack_nchw')
             bufs = [torch.empty(B, H, W, self.num_feat, dtype=dt, device=dev) for _ in range(2)]
             for i, ly in enumerate(layers):
                 last = i == len(layers) - 1
