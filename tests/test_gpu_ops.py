@@ -628,6 +628,65 @@ def test_conv_mfma_bf16_plain(L, cin, cout, h, w):
     assert (got2 - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize('segs,cout,h,w,ups,cb,two_res', [
+    ([64], 64, 50, 70, 0, 32, True),        # SRVGG / conv_body shape: 24-row tiles, ragged bottom and right edges
+    ([64], 64, 13, 21, 1, 8, False),        # conv_up1 / conv_up2: nearest-2x folded into the copies, 8-channel blocks
+    ([64, 32, 32], 32, 37, 45, 0, 32, False),  # dense-block conv3 of a plain RRDBNet: three segments, 32-row tiles
+    ([64, 32, 32, 32], 32, 9, 33, 0, 0, False),  # 160 -> 32: 16-row tiles (weights leave room for 4-row strips only), NHWC
+    ([32], 32, 40, 31, 0, 32, True)])
+def test_conv_plain_wave_autonomous_kernel(L, segs, cout, h, w, ups, cb, two_res):
+    """conv_plain.hip (shared weights, no bands, weights resident in LDS) against an fp64 conv of the same bf16 operands and
+    against conv.hip's producer / consumer kernel on the same device tensors (sr_debug_no_plain_kernel): layouts, the
+    upsample fold, PReLU slopes, residual operands, tile edges."""
+    lib = L.lib()
+    B = 2
+    H, W = h << ups, w << ups
+    cin = sum(segs)
+    xs = [bf(rnd((B, c, h, w), 160 + i)) for i, c in enumerate(segs)]
+    wt = bf(rnd((cout, cin, 3, 3), 170, 0.1))
+    bias = rnd((cout,), 171)
+    slope = torch.rand(cout, generator=torch.Generator().manual_seed(172)) * 0.5
+    r1, r2 = bf(rnd((B, cout, H, W), 173)), bf(rnd((B, cout, H, W), 174))
+    lay = (lambda t: blocked(t, torch.bfloat16, cb)) if cb else (lambda t: nhwc(t, torch.bfloat16))
+    mk = L.blocked_view if cb else L.view
+    xd = [lay(x) for x in xs]
+    cc = L.Concat()
+    cc.nseg, cc.ups = len(xs), ups
+    for i, t in enumerate(xd):
+        cc.x[i] = mk(t)
+    wd = dev(wt.permute(2, 3, 0, 1).reshape(9, cout, cin)).contiguous().to(torch.bfloat16)
+    bd, sd_ = dev(bias), dev(slope)
+    r1d, r2d = lay(r1), lay(r2)
+    ep = L.Epilogue()
+    ep.bias, ep.slope = bd.data_ptr(), sd_.data_ptr()
+    ep.r1, ep.s1 = mk(r1d), 0.2
+    if two_res:
+        ep.r2, ep.s2 = mk(r2d), 0.3
+    outs = []
+    for off in (0, 1):
+        out = lay(torch.full((B, cout, H, W), float('nan')))
+        lib.sr_debug_no_plain_kernel(off)
+        try:
+            L.check(lib.sr_conv3x3(1, B, H, W, C.byref(cc), None, wd.data_ptr(), 0, 0, cout, C.byref(ep), mk(out), st(L)))
+            torch.cuda.synchronize()
+        finally:
+            lib.sr_debug_no_plain_kernel(0)
+        outs.append(unblocked(out) if cb else nchw(out))
+    x = torch.cat(xs, 1).double()
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    y = F.conv2d(x, wt.double(), padding=1) + bias.double().view(1, -1, 1, 1)
+    y = torch.where(y > 0, y, y * slope.double().view(1, -1, 1, 1))
+    y = y * 0.2 + r1.double()
+    if two_res:
+        y = y * 0.3 + r2.double()
+    tol = 2.0 ** -8 * max(1.0, y.abs().max().item())
+    assert torch.isfinite(outs[0]).all()
+    assert (outs[0].double() - y).abs().max().item() < tol
+    # same products, same fp32 accumulation per output: the two kernels differ by summation order at most
+    assert (outs[0] - outs[1]).abs().max().item() <= 2.0 ** -7 * max(1.0, y.abs().max().item())
+
+
 @pytest.mark.parametrize('cb', [8, 32])
 def test_conv_and_gates_channel_blocked_layout(L, cb):
     """bf16 MFMA conv + gates with channel-blocked activations, bands and output, NHWC upsampled source."""
