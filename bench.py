@@ -495,12 +495,24 @@ def main():
     ap.add_argument('--no-split-weights', action='store_true', help='A/B: plain bf16 dynamic weights instead of hi + lo pairs')
     args = ap.parse_args()
 
+    if os.environ.get('SR_BENCH_FAULT_S'):  # debugging aid: dump every thread's Python stack after N seconds (a hung collective)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['SR_BENCH_FAULT_S']), exit=False)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    # SR_BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the N > 1 code paths on a one-GPU box (ranks share the
+    # card, collectives go through the host); the driver's runs use RCCL ('nccl'), one rank per GPU
+    backend = os.environ.get('SR_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    if backend != 'nccl' and ndev:
+        local = local % ndev
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

@@ -203,16 +203,20 @@ class RealESRGANer():
         # therefore needs neither tags (RCCL ignores them) nor an agreed execution order, and no receive kernel sits in
         # front of rank 0's compute.
         mine = self.shard_of(wins, rank, world)
+        # gloo moves host memory only: GPU cores then travel through the host (rehearsals of the N > 1 path on one GPU;
+        # RCCL, the backend of every real multi-GPU run, sends device buffers directly)
+        via_host = self.img.is_cuda and getattr(dist, 'get_backend', lambda: 'nccl')() == 'gloo'
         if rank == 0:
             self._run_tiles(wins, mine, sink=paste)
             stacks = []
             for src in range(1, world):
                 layout, total = self.shard_layout(wins, src, world, batch, channel, s)
-                stacks.append((layout, self.img.new_empty(total)))
+                stacks.append((layout, self.img.new_empty(total, device='cpu' if via_host else self.img.device)))
             ops = [dist.P2POp(dist.irecv, buf, src) for src, (_, buf) in enumerate(stacks, start=1) if buf.numel()]
             for r in (dist.batch_isend_irecv(ops) if ops else []):
                 r.wait()
             for layout, buf in stacks:
+                buf = buf.to(self.img.device)
                 for i, off, shape in layout:
                     paste(i, buf[off:off + math.prod(shape)].view(shape))
         else:
@@ -226,7 +230,7 @@ class RealESRGANer():
                 stack[off:off + math.prod(shape)].view(shape).copy_(t)
             self._run_tiles(wins, mine, sink=pack)
             if total:
-                for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, stack, 0)]):
+                for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, stack.cpu() if via_host else stack, 0)]):
                     r.wait()
 
     def post_process(self):

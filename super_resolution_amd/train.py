@@ -896,7 +896,14 @@ class FlatAdam(torch.optim.Optimizer):
                                '.to() / .float() / .cuda() after the optimizer was built) -- rebuild the optimizer')
         g = self.gather_gradients()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+            if g.is_cuda and dist.get_backend(group) == 'gloo':
+                # gloo reduces host memory (its device path stalls when ranks share one GPU: seen with two ranks on one
+                # MI355X); RCCL -- every real multi-GPU run -- reduces the device buffer in place
+                h = g.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                g.copy_(h)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
             if average:
                 g /= dist.get_world_size(group)
         if clip_grad_norm is not None:  # nn.utils.clip_grad_norm_: scale by max_norm / (norm + 1e-6), clamped to 1
