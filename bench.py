@@ -102,9 +102,14 @@ def synthetic_batch(B, H, W, device, seed=1234):
     return x.to(device)
 
 
-def build_model(device, ch=1, seed=1234):
+def build_model(device, ch=1, seed=1234, plain=False):
     import golden_params as gp
     from super_resolution_amd import RRDBNet, replace_conv_with_fdconv
+    if plain:  # RealESRGAN_x4plus's architecture (inference_realesrgan.py:59-62): RRDBNet's own seeded initialisation, no FDConv
+        torch.manual_seed(seed)
+        net = RRDBNet(ch, ch, 4, NUM_FEAT, NUM_BLOCK, NUM_GROW)
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}  # CPU copy for the oracle leg, taken before the move
+        return net.eval().to(device), sd
     net = replace_conv_with_fdconv(RRDBNet(ch, ch, 4, NUM_FEAT, NUM_BLOCK, NUM_GROW))
     sd = {k: torch.from_numpy(v) for k, v in gp.rrdbnet_state(ch, ch, NUM_FEAT, NUM_BLOCK, NUM_GROW, seed=seed).items()}
     net.load_state_dict(sd, strict=True)
@@ -221,7 +226,7 @@ def run_batch(args, world, rank, dev, dist):
 
 def run_tiled(args, world, rank, dev, dist):
     from super_resolution_amd import RealESRGANer
-    net, sd = build_model(dev, 3)
+    net, sd = build_model(dev, 3, plain=args.plain)
     side = args.image
     img = (np.random.default_rng(1234).random((side, side, 3)) * 255).astype(np.uint8)
     r = RealESRGANer(scale=4, model_path=None, model=net, tile=args.tile, tile_pad=args.tile_pad, pre_pad=0, half=True,
@@ -315,7 +320,8 @@ def run_tiled(args, world, rank, dev, dist):
         'warmup': max(args.warmup, 1), 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'RealESRGANer(tile=%d, tile_pad=%d, pre_pad=0, half=True) x4 on one %dx%d synthetic RGB image, '
-                               'RRDBNet-FDConv(3,3,64,23,32), bf16 (BASELINE.json configs[2])' % (args.tile, args.tile_pad, side, side),
+                               '%s, bf16 (BASELINE.json configs[2])' % (args.tile, args.tile_pad, side, side,
+                                                                       'plain RRDBNet(3,3,64,23,32) = RealESRGAN_x4plus architecture (configs[0] network)' if args.plain else 'RRDBNet-FDConv(3,3,64,23,32)'),
                    'tiles': len(wins), 'tile_batch': args.tile_batch,
                    'parallelism': '%d tiles area-sorted round-robin over %d rank(s), one p2p message per peer (its cores stacked in shard order) to rank 0, no collective' % (len(wins), world),
                    'timed_region': 'tile_process() + post_process() with the padded image resident in HBM; max over ranks incl. the gather',
@@ -486,6 +492,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--image', type=int, default=4096, help='tiled: side of the square RGB image')
+    ap.add_argument('--plain', action='store_true', help='tiled: the plain RRDBNet (RealESRGAN_x4plus architecture, BASELINE configs[0] network) instead of RRDBNet-FDConv')
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--tile-pad', type=int, default=10)
     ap.add_argument('--tile-batch', type=int, default=18, help='tiled: tiles of equal window size per forward (8 -> 18: 45.7 -> 49.2 out-Mpix/s at N = 1)')
@@ -540,14 +547,15 @@ def main():
         import copy
         import gc
         res['secondary'] = {}
-        for name in ('tiled', 'train', 'srvgg'):
+        for name in ('tiled', 'tiled_plain', 'train', 'srvgg'):
             gc.collect()
             torch.cuda.empty_cache()
             a2 = copy.copy(args)
             a2.steps, a2.warmup, a2.no_cpu_baseline = (3 if name == 'srvgg' else 1), 1, True
+            a2.plain = name == 'tiled_plain'
             t0 = time.perf_counter()
             try:
-                r2 = runners[name](a2, world, rank, dev, dist)
+                r2 = runners['tiled' if name == 'tiled_plain' else name](a2, world, rank, dev, dist)
                 res['secondary'][name] = {'value': r2['value'], 'unit': r2['unit'], 'ms_per_step': r2['ms_per_step'], 'steps': a2.steps,
                                           'dtype': r2['dtype'], 'scaling': r2['scaling'], 'workload': r2['config']['workload'],
                                           'roofline_bound': r2['roofline']['bound'], 'roofline_frac': r2['roofline']['frac'],
