@@ -13,7 +13,7 @@ synthetic batch of 16 grayscale 512x512 images already resident in HBM, bf16 (MF
 shards by batch with no exchange step, so every rank runs the same per-GPU batch ("weak").
 --config tiled: a step = RealESRGANer(tile=512, tile_pad=10, pre_pad=0, half=True, shard_tiles=True).tile_process()
 + post_process() of one 4096x4096 RGB image that pre_process has already placed in HBM, RRDBNet-FDConv(3,3,64,23,32);
-the 64 tiles are dealt area-sorted round-robin over the N ranks and rank 0 gathers the cores point to point
+the 64 tiles, sorted by window shape, go to the N ranks in contiguous blocks and rank 0 gathers the cores point to point
 ("strong": the image is fixed).  The host-to-host enhance() time and the non-parallel share are reported beside it.
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
@@ -323,7 +323,7 @@ def run_tiled(args, world, rank, dev, dist):
                                '%s, bf16 (BASELINE.json configs[2])' % (args.tile, args.tile_pad, side, side,
                                                                        'plain RRDBNet(3,3,64,23,32) = RealESRGAN_x4plus architecture (configs[0] network)' if args.plain else 'RRDBNet-FDConv(3,3,64,23,32)'),
                    'tiles': len(wins), 'tile_batch': args.tile_batch,
-                   'parallelism': '%d tiles area-sorted round-robin over %d rank(s), one p2p message per peer (its cores stacked in shard order) to rank 0, no collective' % (len(wins), world),
+                   'parallelism': '%d tiles sorted by window shape, one contiguous block per rank over %d rank(s), one p2p message per peer (its cores stacked in shard order) to rank 0, no collective' % (len(wins), world),
                    'timed_region': 'tile_process() + post_process() with the padded image resident in HBM; max over ranks incl. the gather',
                    'enhance_host_to_host_s': t_enh, 'enhance_host_to_host_out_mpix_s': out_mpix / t_enh,
                    'pre_process_s': t_pre,

@@ -176,13 +176,17 @@ class _Identity(torch.nn.Module):
 @pytest.mark.parametrize('tile_batch', [1, 18])
 def test_tile_gather_is_order_safe_at_config3_geometry(world, tile_batch, monkeypatch):
     """BASELINE configs[2] geometry (4096^2, tile 512, pad 10) under RCCL's matching rule.  The order a rank RUNS its tiles
-    in (grouped by window shape) differs from its shard_of() order; the gather must paste every core at its own place
+    in may differ from its shard_of() order (here it is reversed on purpose); the gather must paste every core at its own place
     all the same (round 2 paired per-tile sends and receives by tag and mis-pasted edge tiles)."""
     import torch.distributed as real_dist
     from super_resolution_amd import RealESRGANer
     fake = _FifoDist(world)
     for name in ('is_available', 'is_initialized', 'get_world_size', 'get_rank', 'isend', 'irecv', 'batch_isend_irecv', 'P2POp'):
         monkeypatch.setattr(real_dist, name, getattr(fake, name))
+    # shard_of() hands out shape-sorted blocks, so batches_of() would run them in shard order: run them backwards
+    plain_batches = RealESRGANer.batches_of
+    monkeypatch.setattr(RealESRGANer, 'batches_of', staticmethod(
+        lambda wins, idxs, tile_batch: [part[::-1] for part in plain_batches(wins, idxs, tile_batch)][::-1]))
     img = torch.rand(4096, 4096, 1, generator=torch.Generator().manual_seed(world)).numpy()
     out, reordered = None, 0
     for rank in list(range(1, world)) + [0]:

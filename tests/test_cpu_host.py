@@ -144,7 +144,13 @@ def test_tile_windows_and_sharding():
     assert sorted(sum(shards, [])) == list(range(64)) and all(len(s) == 8 for s in shards)
     area = lambda i: (wins[i][0][1] - wins[i][0][0]) * (wins[i][0][3] - wins[i][0][2])
     loads = [sum(area(i) for i in s) for s in shards]
-    assert max(loads) / min(loads) < 1.02
+    assert max(loads) / min(loads) < 1.03
+    # one contiguous shape-sorted block per rank: at most two window shapes (= forwards) on a rank, one on most
+    shapes = [len({(wins[i][0][1] - wins[i][0][0], wins[i][0][3] - wins[i][0][2]) for i in s}) for s in shards]
+    assert max(shapes) <= 2 and shapes.count(1) >= 6
+    for world in (1, 2, 3, 5, 64, 70):  # any world size partitions the tiles (ranks beyond the tile count get none)
+        parts = [r.shard_of(wins, k, world) for k in range(world)]
+        assert sorted(sum(parts, [])) == list(range(64)) and max(map(len, parts)) - min(map(len, parts)) <= 1
     # whole pipeline on the CPU with a stand-in network: tiled == whole for a pointwise model
     img = gp.image_input((37, 53, 3), 5)
     r = RealESRGANer(scale=4, model_path=None, model=Up(), tile=16, tile_pad=3, pre_pad=5, device=torch.device('cpu'))
