@@ -24,6 +24,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                  head convs against the HBM roof on their strict bytes;
   cpu_baseline : the CPU oracle (torch fp32 restatement pinned by the golden fixtures) timed on this host on a
                  bounded sample of the same workload.
+  secondary    : (default config only) one short timed step of each other BASELINE config; at N > 1 the ones that shard
+                 -- the tiled image over the N ranks (strong scaling) and the training step with its all-reduce.
 """
 import argparse
 import glob
@@ -498,7 +500,8 @@ def main():
     ap.add_argument('--tile-batch', type=int, default=18, help='tiled: tiles of equal window size per forward (8 -> 18: 45.7 -> 49.2 out-Mpix/s at N = 1)')
     ap.add_argument('--cpu-sample', type=int, default=128, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
-    ap.add_argument('--no-secondary', action='store_true', help='batch: skip the one-step runs of the tiled / train / srvgg configs')
+    ap.add_argument('--no-secondary', action='store_true', help='batch: skip the one-step runs of the tiled / train / srvgg configs (N > 1: tiled and train, sharded over the ranks)')
+    ap.add_argument('--secondary-deadline', type=int, default=420, help='batch: seconds the secondary configs may take before the headline is printed without them')
     ap.add_argument('--no-split-weights', action='store_true', help='A/B: plain bf16 dynamic weights instead of hi + lo pairs')
     args = ap.parse_args()
 
@@ -541,13 +544,27 @@ def main():
         _lib.lib().sr_debug_split_weights(0)
     runners = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch, 'train': run_train}
     res = runners[args.config](args, world, rank, dev, dist)
-    if args.config == 'batch' and world == 1 and not args.no_secondary:
-        # the other BASELINE configs, one short timed step each, so that the driver's one command sees them too
-        # (each also runs on its own and at N > 1 with --config)
+    if args.config == 'batch' and not args.no_secondary:
+        # the other BASELINE configs, one short timed step each, so that the driver's one command sees them too (each also
+        # runs on its own with --config).  At N > 1 the configs that shard run as well -- the tiled image over the N ranks
+        # (strong scaling, p2p gather) and the training step with its gradient all-reduce -- so the driver's 1/2/4/8-GPU
+        # runs of this one command carry north_star's tiled-scaling figure.  A deadline guards the headline: if a secondary
+        # config is still running when it passes (a collective that never completes), rank 0 prints the headline line
+        # with the secondary marked abandoned and every rank leaves.
         import copy
         import gc
+        import threading
+        finished = threading.Event()
+        fallback = json.dumps(dict(res, secondary={'error': 'secondary configs abandoned after %d s' % args.secondary_deadline}))
+
+        def watch():
+            if not finished.wait(args.secondary_deadline):
+                if rank == 0:
+                    print(fallback, flush=True)
+                os._exit(0)
+        threading.Thread(target=watch, daemon=True).start()
         res['secondary'] = {}
-        for name in ('tiled', 'tiled_plain', 'train', 'srvgg'):
+        for name in (('tiled', 'tiled_plain', 'train', 'srvgg') if world == 1 else ('tiled', 'tiled_plain', 'train')):
             gc.collect()
             torch.cuda.empty_cache()
             a2 = copy.copy(args)
@@ -557,12 +574,15 @@ def main():
             try:
                 r2 = runners['tiled' if name == 'tiled_plain' else name](a2, world, rank, dev, dist)
                 res['secondary'][name] = {'value': r2['value'], 'unit': r2['unit'], 'ms_per_step': r2['ms_per_step'], 'steps': a2.steps,
-                                          'dtype': r2['dtype'], 'scaling': r2['scaling'], 'workload': r2['config']['workload'],
+                                          'n_gpus': world, 'dtype': r2['dtype'], 'scaling': r2['scaling'], 'workload': r2['config']['workload'],
                                           'roofline_bound': r2['roofline']['bound'], 'roofline_frac': r2['roofline']['frac'],
                                           'detail': {k: v for k, v in r2['config'].items() if k not in ('workload',)},
                                           'wall_s': time.perf_counter() - t0}
             except Exception as e:  # a secondary config must never take the headline line down with it
                 res['secondary'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
+                if world > 1:  # the peers may already be inside the next collective: do not join them half-way
+                    break
+        finished.set()
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
