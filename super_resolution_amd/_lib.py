@@ -128,6 +128,8 @@ _SIGS = {
     'sr_rrdbnet_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]),
     'sr_debug_force_generic_conv': (None, [C.c_int]),
     'sr_debug_force_generic_fft': (None, [C.c_int]),
+    'sr_debug_no_mixed_fft': (None, [C.c_int]),
+    'sr_debug_last_lowpass_path': (C.c_int, []),
     'sr_debug_force_fft_lowpass': (None, [C.c_int]),
     'sr_debug_no_ups_shortcut': (None, [C.c_int]),
     'sr_debug_gates_no_direct': (None, [C.c_int]),

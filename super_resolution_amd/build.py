@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['layout.hip', 'fbm.hip', 'fbm_fast.hip', 'fbm_mfma.hip', 'gates.hip', 'weightgen.hip', 'weightgen_bwd.hip', 'conv.hip', 'conv_plain.hip', 'net.hip', 'head.hip', 'train.hip']
+SOURCES = ['layout.hip', 'fbm.hip', 'fbm_fast.hip', 'fbm_fast_mixed.hip', 'fbm_mfma.hip', 'gates.hip', 'weightgen.hip', 'weightgen_bwd.hip', 'conv.hip', 'conv_plain.hip', 'net.hip', 'head.hip', 'train.hip']
 OUT = os.path.join(HERE, 'libsr_amd.so')
 
 

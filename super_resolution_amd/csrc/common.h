@@ -219,6 +219,9 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 #define SR_NOT_ELIGIBLE (-100)
 int fbm_lowpass_pow2(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
                      int pooled_ld, void* ws, hipStream_t st, int bmask = 7);
+// the same kernels for the mixed-radix sides 1044 / 1064 / 2088 / 2128 (high-resolution tensors of tiles at tile 512, pad 10)
+int fbm_lowpass_mixed(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
+                      int pooled_ld, void* ws, hipStream_t st, int bmask = 7);
 // bf16 only: the three passes as real-basis DFT GEMMs on the matrix cores (SR_NOT_ELIGIBLE otherwise)
 int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, View l2, View l4, View l8, float* pooled,
                      int pooled_ld, void* ws, hipStream_t st, int bmask = 7);

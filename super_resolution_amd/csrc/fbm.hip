@@ -564,6 +564,8 @@ __global__ __launch_bounds__(1024) void fbm_rows_inv(View l2, View l4, View l8, 
 }
 
 int g_force_generic_fft = 0;  // test hook
+int g_no_mixed_fft = 0;       // test / A-B hook
+int g_last_lowpass_path = -1; // test hook: kernel family of the last launch (0 generic FFT, 1 power-of-two FFT, 2 mixed-radix FFT, 3 DFT-as-GEMM)
 namespace fast {
 extern int g_no_ups_shortcut;  // debug hook (fbm_fast.hip): full-length transforms of upsampled sources
 }
@@ -595,12 +597,15 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
     if (ws_bytes < sr_fbm_workspace_bytes(pl, B, C)) return SR_ERR_WORKSPACE;
     if (!g_force_generic_fft && !g_force_fft_lowpass) {
         const int rc = fbm_lowpass_mfma(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st, bmask);
-        if (rc != SR_NOT_ELIGIBLE) return rc;
+        if (rc != SR_NOT_ELIGIBLE) { g_last_lowpass_path = 3; return rc; }
     }
     if (!g_force_generic_fft) {
-        const int rc = fbm_lowpass_pow2(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st, bmask);
-        if (rc != SR_NOT_ELIGIBLE) return rc;
+        int rc = fbm_lowpass_pow2(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st, bmask);
+        if (rc != SR_NOT_ELIGIBLE) { g_last_lowpass_path = 1; return rc; }
+        if (!g_no_mixed_fft) rc = fbm_lowpass_mixed(pl, dtype, B, x, ups, l2, l4, l8, pooled, pooled_ld, ws, st, bmask);
+        if (rc != SR_NOT_ELIGIBLE) { g_last_lowpass_path = 2; return rc; }
     }
+    g_last_lowpass_path = 0;
     const int n2 = pl->n[0], n4 = pl->n[1], n8 = pl->n[2];
     float2* t1 = (float2*)ws;
     float2* y2 = t1 + (size_t)B * n2 * H * PT;
@@ -669,6 +674,8 @@ int fbm_lowpass_launch(const sr_fbm_plan* pl, int dtype, int B, View x, int ups,
 using namespace sr;
 
 extern "C" void sr_debug_force_generic_fft(int on) { sr::g_force_generic_fft = on; }
+extern "C" int sr_debug_last_lowpass_path(void) { return sr::g_last_lowpass_path; }
+extern "C" void sr_debug_no_mixed_fft(int on) { sr::g_no_mixed_fft = on; }  // 1: the 1044 / 1064 / 2088 / 2128 sides take the generic FFT
 namespace sr { extern int g_mfma_no_fold; }
 extern "C" void sr_debug_mfma_no_fold(int on) { sr::g_mfma_no_fold = on; }
 namespace sr { namespace fast { extern int g_no_ups_shortcut; } }
@@ -798,17 +805,12 @@ extern "C" int sr_fbm_plan_create(int H, int W, sr_fbm_plan** out) {
             pl->ucutH = pair_cut(any, H, Rh);  // >= every tcutH: the inverse passes read only what the forward pass wrote
         }
     }
-    {   // first-pass operand ranges of the pruned inverse column transform (same radix choice as fbm_fast.hip)
-        const int r0 = (H % 8 == 0 && H != 16) ? 8 : (H % 4 == 0 ? 4 : 2), nr0 = H / r0;
-        for (int kv = 0; kv < 9; ++kv) {
-            int m = 0;
-            for (int t = 0; t < r0 && H % r0 == 0; ++t) {
-                bool zero = true;
-                for (int r = t * nr0; r < (t + 1) * nr0; ++r) zero &= rmask[(size_t)kv * H + r] == 0.f;
-                if (zero) m |= 1 << t;
-            }
-            pl->row_zmask[kv] = m;
-        }
+    for (int k = 0; k < 3; ++k) {  // extent of band k along H over its three variants (fbm_fast.h prunes passes by it)
+        int a = 1;
+        for (int v = 0; v < 3; ++v)
+            for (int r = 0; r < H; ++r)
+                if (rmask[(size_t)(k * 3 + v) * H + r] != 0.f) a = std::max(a, std::min(r + 1, H - r + 1));  // r < a or r > H - a
+        pl->row_half[k] = a;
     }
     std::vector<float2> tww(W), twh(H);
     for (int j = 0; j < W; ++j) tww[j] = make_float2((float)cos(-2.0 * M_PI * j / W), (float)sin(-2.0 * M_PI * j / W));

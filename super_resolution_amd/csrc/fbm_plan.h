@@ -25,7 +25,7 @@ struct sr_fbm_plan {
     int tcutH[9];          // inverse along H, [mask k][variant]: operand pairs t >= tcut have zero row-mask weights
     // forward row transform of a nearest-2x upsampled source: one W/2-point transform per source row (fbm_rows_fwd_up)
     int nfWu, radWu[24], Pwu, ucutWu;
-    int row_zmask[9];      // [mask k][variant]: bit t set = rows [t*H/R0, (t+1)*H/R0) of that row mask are all zero (R0 = first radix of H)
+    int row_half[3];       // band k: every variant of its row mask lies inside [0, row_half) u (H - row_half, H) (fbm_fast.h prunes by it)
     // ---- real-basis tables of the MFMA path (fbm_mfma.hip); mf_ok == 0 when the shape / masks are not covered ----
     int mf_ok;
     int mf_jw;             // x-basis functions kept by mask k=2 (DC, dummy, then cos c / sin c pairs) = 2 * half[0]

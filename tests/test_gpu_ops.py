@@ -276,6 +276,71 @@ def test_fbm_lowpass_channel_blocked_layout(L, shape, ups, cb):
     assert (pooled.cpu() - xu.mean(dim=(2, 3))).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize('shape,ups,cb,dt', [
+    ((1, 16, 1044, 1064), 0, 8, torch.float32),    # 4 9 29 x 8 7 19, channel-blocked (the executor's 2x layout)
+    ((2, 8, 532, 522), 1, 8, torch.float32),       # nearest-2x source -> 1064 x 1044: half-length transforms (532, 522)
+    ((1, 6, 1064, 1064), 0, 0, torch.float32),     # NHWC, 3 pairs in a group of 8
+    ((1, 8, 2088, 2128), 0, 8, torch.float32),     # 8 9 29 x 16 7 19
+    ((1, 8, 2128, 2088), 0, 8, torch.bfloat16),
+    ((1, 16, 1064, 1044), 1, 8, torch.bfloat16),   # -> 2128 x 2088 from the 2x tensor (conv_up2)
+    ((1, 8, 2128, 2128), 0, 0, torch.bfloat16),
+])
+def test_fbm_lowpass_mixed_radix_sizes(L, shape, ups, cb, dt):
+    """The register-blocked mixed-radix FFT (fbm_fast_mixed.hip: sides 1044 / 1064 / 2088 / 2128 = the high-resolution
+    tensors of a tile at the reference's default tiling) against the fp64 oracle and against the generic FFT kernels on
+    the same input; one band alone as well (the adjoint of the band mix asks for single bands)."""
+    lib = L.lib()
+    x = torch.from_numpy(gp.signed_input(shape, 23)).to(dt).float()
+    B, Cc, H, W = x.shape
+    Ho, Wo = H << ups, W << ups
+    xu = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    ref = fr.fbm_lowpass(xu.double(), torch.float64)
+
+    def run(want=(0, 1, 2)):
+        plan = C.c_void_p()
+        L.check(lib.sr_fbm_plan_create(Ho, Wo, C.byref(plan)))
+        if cb:
+            xin = blocked(x, dt, cb)
+            bands = [torch.full((B, Cc // cb, Ho, Wo, cb), float('nan'), device='cuda:0', dtype=dt) for _ in range(3)]
+            vx, vb = L.blocked_view(xin), [L.blocked_view(b) if k in want else L.null_view() for k, b in enumerate(bands)]
+        else:
+            xin = dev(x).permute(0, 2, 3, 1).contiguous().to(dt)
+            bands = [torch.full((B, Ho, Wo, Cc), float('nan'), device='cuda:0', dtype=dt) for _ in range(3)]
+            vx, vb = L.view(xin), [L.view(b) if k in want else L.null_view() for k, b in enumerate(bands)]
+        pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
+        ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+        L.check(lib.sr_fbm_lowpass(plan, L.dtype_code(dt), B, vx, ups, vb[0], vb[1], vb[2], pooled.data_ptr(), Cc, ws.data_ptr(),
+                                   ws.numel(), st(L)))
+        torch.cuda.synchronize()
+        path = lib.sr_debug_last_lowpass_path()
+        lib.sr_fbm_plan_destroy(plan)
+        out = [unblocked(b) if cb else b.float().permute(0, 3, 1, 2).cpu() for b in bands]
+        return out, pooled.cpu(), path
+
+    lib.sr_debug_force_fft_lowpass(1)
+    try:
+        got, pooled, path = run()
+        assert path == 2, path
+        one, _, path1 = run(want=(1,))
+        assert path1 == 2
+        lib.sr_debug_no_mixed_fft(1)
+        try:
+            gen, pooled_gen, path_gen = run()
+        finally:
+            lib.sr_debug_no_mixed_fft(0)
+        assert path_gen == 0, path_gen
+    finally:
+        lib.sr_debug_force_fft_lowpass(-1)
+    tol = 2e-5 if dt == torch.float32 else 2.0 ** -8  # bf16: half an ulp of values below 2
+    for k in range(3):
+        err = (got[k].double() - ref[k]).abs().max().item()
+        assert err < tol, (k, err)
+        assert (got[k] - gen[k]).abs().max().item() < (2e-5 if dt == torch.float32 else 2.0 ** -7), k
+    assert torch.equal(one[1], got[1]) and torch.isnan(one[0]).all() and torch.isnan(one[2]).all()
+    assert (pooled.double() - xu.double().mean(dim=(2, 3))).abs().max().item() < 1e-5
+    assert (pooled - pooled_gen).abs().max().item() < 1e-6
+
+
 def test_fbm_lowpass_upsampled_and_bf16(L):
     x = torch.from_numpy(gp.signed_input((2, 8, 20, 24), 12))
     xu = F.interpolate(x, scale_factor=2, mode='nearest')
