@@ -255,8 +255,14 @@ __device__ __forceinline__ void fft(float2* __restrict__ buf, const float2* __re
 
 extern __shared__ __attribute__((aligned(16))) char smem_fast[];
 
-template <int N>
+// Twiddles exp(-2 pi i j / N) are staged in LDS behind the working set -- unless that pushes a workgroup past half of a
+// CU's 160 KiB (the 2088 / 2128-point sides at 4 pairs: 68 + 17 KiB): those read the 17 KiB table through L1 / L2 instead
+// and two workgroups share a CU.
+constexpr bool twiddles_in_lds(int n, int p) { return (size_t)(n * p + n) * sizeof(float2) <= 80 * 1024; }
+constexpr size_t lds_bytes(int n, int p) { return (size_t)n * p * sizeof(float2) + (twiddles_in_lds(n, p) ? (size_t)n * sizeof(float2) : 0); }
+template <int N, int P>
 __device__ __forceinline__ const float2* stage_twiddles(const float2* __restrict__ tw, float2* twl) {
+    if constexpr (!twiddles_in_lds(N, P)) return tw;
     for (int i = threadIdx.x; i < N; i += THREADS) twl[i] = tw[i];
     __syncthreads();
     return twl;
@@ -343,7 +349,8 @@ constexpr int band_zm(int k) { return PZ ? range_mask(N, first_radix(N), band_am
 constexpr int last_radix(int n) { return pick_radix<false>(n) == n ? n : last_radix(n / pick_radix<false>(n)); }
 template <int N, bool PZ>
 constexpr int fwd_oz() { return PZ ? range_mask(N, last_radix(N), band_amax(N, 0)) : 0; }
-constexpr int min_waves(int n) { return (n & (n - 1)) == 0 ? 4 : 2;  }  // radix-19 / 29 butterflies need the registers
+// waves per SIMD the register budget is set for: radix-29 butterflies and the unpruned fallback instances need more than 128
+constexpr int min_waves(int n, bool pz) { return (n % 29 == 0 || (!pz && (n & (n - 1)) != 0)) ? 2 : 4; }
 
 
 // ---- rows forward -------------------------------------------------------------------------
@@ -351,7 +358,7 @@ template <typename T, int N, int P, bool BLK, bool PZ>
 __global__ __launch_bounds__(THREADS) void rows_fwd(View x, int ups, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, float2* __restrict__ t1) {
     float2* buf = (float2*)smem_fast;
-    const float2* twl = stage_twiddles<N>(tw, buf + N * P);
+    const float2* twl = stage_twiddles<N, P>(tw, buf + N * P);
     unsigned bx, by;
     block_xy(im, bx, by);
     const int b = bx / H, h = bx % H;
@@ -414,14 +421,14 @@ __global__ __launch_bounds__(THREADS) void rows_fwd_up(View x, int H, int PT, In
 
 // ---- columns: forward, mask, inverse x3 ------------------------------------------------------
 template <int N, int P, bool BLK, bool PZ, bool UPS = false>
-__global__ __launch_bounds__(THREADS, min_waves(N)) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
+__global__ __launch_bounds__(THREADS, min_waves(N, PZ)) void cols(int W, int PT, Inter im, const float2* __restrict__ tw, int a2, int a4,
                                                 int a8, const float* __restrict__ rowmask,
                                                 const float2* __restrict__ t1, float2* __restrict__ y2,
                                                 float2* __restrict__ y4, float2* __restrict__ y8,
                                                 float* __restrict__ pooled, int pooled_ld, int C, int bmask) {
     constexpr int H = N;
     float2* buf = (float2*)smem_fast;
-    const float2* twl = stage_twiddles<N>(tw, buf + N * P);
+    const float2* twl = stage_twiddles<N, P>(tw, buf + N * P);
     const int n2 = 2 * a2 - 1;
     unsigned bx, by;
     block_xy(im, bx, by);
@@ -504,12 +511,12 @@ __global__ __launch_bounds__(THREADS, min_waves(N)) void cols(int W, int PT, Int
 
 // ---- rows inverse -------------------------------------------------------------------------
 template <typename T, int N, int P, bool BLK, bool PZ>
-__global__ __launch_bounds__(THREADS, min_waves(N)) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
+__global__ __launch_bounds__(THREADS, min_waves(N, PZ)) void rows_inv(View l2, View l4, View l8, int H, int PT, Inter im,
                                                     const float2* __restrict__ tw, int a2, int a4, int a8,
                                                     const float2* __restrict__ y2, const float2* __restrict__ y4,
                                                     const float2* __restrict__ y8, int bmask) {
     float2* buf = (float2*)smem_fast;
-    const float2* twl = stage_twiddles<N>(tw, buf + N * P);
+    const float2* twl = stage_twiddles<N, P>(tw, buf + N * P);
     unsigned bx, by;
     block_xy(im, bx, by);
     const int b = bx / H, h = bx % H;
@@ -596,7 +603,7 @@ static int launch_rows_fwd(View x, int ups, bool shortcut, int B, int H, int PT,
         }
     }
     constexpr int P = pairs_for(N);
-    const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
+    const size_t lds = lds_bytes(N, P);
     // kept columns of the widest mask inside the outer quarters: the last pass skips the middle half of its outputs
     const bool pz = pl->half[0] <= band_amax(N, 0) && fwd_oz<N, true>() != 0;
     if (pz) {
@@ -614,7 +621,7 @@ template <typename T, int N, bool BLK>
 static int launch_rows_inv(View l2, View l4, View l8, int B, int H, int PT, Inter im, const sr_fbm_plan* pl,
                            const float2* y2, const float2* y4, const float2* y8, int bmask, hipStream_t st) {
     constexpr int P = pairs_for(N);
-    const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
+    const size_t lds = lds_bytes(N, P);
     // standard band extents along W: the operand ranges of the first pass that band_zm names are empty
     const bool pz = pl->half[0] <= band_amax(N, 0) && pl->half[1] <= band_amax(N, 1) && pl->half[2] <= band_amax(N, 2) &&
                     (band_zm<N, true>(0) | band_zm<N, true>(1) | band_zm<N, true>(2)) != 0;
@@ -635,7 +642,7 @@ template <int N, bool BLK>
 static int launch_cols(bool shortcut, int B, int W, int PT, int C, Inter im, const sr_fbm_plan* pl, const float2* t1, float2* y2,
                        float2* y4, float2* y8, float* pooled, int pooled_ld, int bmask, hipStream_t st) {
     constexpr int P = pairs_for(N);
-    const size_t lds = (size_t)N * P * sizeof(float2) + (size_t)N * sizeof(float2);
+    const size_t lds = lds_bytes(N, P);
     // every variant of every row mask must lie inside the standard band extents
     const bool pz = pl->row_half[0] <= band_amax(N, 0) && pl->row_half[1] <= band_amax(N, 1) && pl->row_half[2] <= band_amax(N, 2) &&
                     (band_zm<N, true>(0) | band_zm<N, true>(1) | band_zm<N, true>(2) | fwd_oz<N, true>()) != 0;
