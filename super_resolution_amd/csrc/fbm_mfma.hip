@@ -372,7 +372,11 @@ struct SynArgs {
 // fp16 out);  false: synthesis along W (one image per band, bf16 views out).
 // KS = k-steps of 16 (16: K <= 256; 17: K <= 272, the 522 / 532-pixel windows of a tiled image -- with the window image
 // that is exactly the 160 KiB of LDS).
-template <bool SHARED, int KS>
+// SOLO (synthesis along H of the 522 / 532-row windows): the launch serves ONE basis tile, a.tile0 -- the 17th, which the
+// 16 tiles in the registers of the first launch leave over.  Wave g < 4 multiplies item g of every group by it and waves
+// 4..7 only stage; without it all eight waves computed that tile twice over (clamped tile indices), i.e. the second
+// launch repeated the MFMA work of the first for 20 of 532 rows.
+template <bool SHARED, int KS, bool SOLO = false>
 __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
     constexpr int G = 4, ROWB = 256;
     constexpr int IMG = KS * 16 * ROWB;        // bytes of one staged image
@@ -384,12 +388,13 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
     // M is a multiple of 32 (host); tiles beyond the last one repeat it, items beyond the last one repeat it (the loader
     // clamps the same way): no predicate around the stores, see mf_analysis
     const int NT = a.M >> 5;
-    const int tj[2] = {min(a.tile0 + 2 * wave, NT - 1), min(a.tile0 + 2 * wave + 1, NT - 1)};
-    half8 bq[KS][2];
+    constexpr int NJ = SOLO ? 1 : 2;  // basis tiles per wave
+    const int tj[2] = {SOLO ? min(a.tile0, NT - 1) : min(a.tile0 + 2 * wave, NT - 1), min(a.tile0 + 2 * wave + 1, NT - 1)};
+    half8 bq[KS][NJ];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
             bq[ks][j] = ks < a.nks_tab ? *(const half8*)(a.basis + ((size_t)(tj[j] * a.nks_tab + ks) * 64 + lane) * 8) : zero_h8();
     // !SHARED with 17 basis tiles (the 522 / 532-pixel rows of a tiled image: 544 columns, 16 tiles in the waves' registers):
     // the 17th tile's fragments live in the window-image region of LDS, which the W-synthesis does not use, and waves 0..3
@@ -510,37 +515,35 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                     d[0] = lo;
                     d[1] = hi;
                 };
-                uint4 held[2][2][2];  // packed rows of items 0 and 1, kept until the next image has been staged
+                uint4 held[2][NJ][2];  // packed rows of items 0 and 1, kept until the next image has been staged
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const int ta0 = tr_addr<G>(lane, g, 0), ta1 = tr_addr<G>(lane, g, 1);
-                    // k-steps 0 .. kend - 1: the loop leaves early instead of branching around every step (an exit edge
-                    // keeps the accumulators where they are, a skipped step costs a copy of them at the join)
-                    f32x16 acc[2];
+                    if (!SOLO || wave == g) {  // wave-uniform
+                        const int ta0 = tr_addr<G>(lane, g, 0), ta1 = tr_addr<G>(lane, g, 1);
+                        // k-steps 0 .. kend - 1: the loop leaves early instead of branching around every step (an exit edge
+                        // keeps the accumulators where they are, a skipped step costs a copy of them at the join)
+                        f32x16 acc[NJ];
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        if (ks && ks >= kend) break;
-                        const char* base = img + ks * 16 * ROWB;
-                        if (SHARED) base = ks < ksm ? base : wbase + ks * 16 * ROWB;
-                        const half8 d = tr_read(base, ta0, ta1);
-                        if (ks == 0) {
+                        for (int ks = 0; ks < KS; ++ks) {
+                            if (ks && ks >= kend) break;
+                            const char* base = img + ks * 16 * ROWB;
+                            if (SHARED) base = ks < ksm ? base : wbase + ks * 16 * ROWB;
+                            const half8 d = tr_read(base, ta0, ta1);
                             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][0], z, 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][1], z, 0, 0, 0);
-                        } else {
-                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][0], acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][1], acc[1], 0, 0, 0);
-                        }
-                    }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        uint4 lo, hi;
-                        tile_to_rows<!SHARED>(acc[j], 1.0f, lo, hi);
-                        if (g < 2) {
-                            held[g][j][0] = lo;
-                            held[g][j][1] = hi;
-                        } else {
-                            store(g, j, lo, hi);
+                            for (int j = 0; j < NJ; ++j)
+                                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, bq[ks][j], ks == 0 ? z : acc[j], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            uint4 lo, hi;
+                            tile_to_rows<!SHARED>(acc[j], 1.0f, lo, hi);
+                            if (g < 2) {
+                                held[g][j][0] = lo;
+                                held[g][j][1] = hi;
+                            } else {
+                                store(g, j, lo, hi);
+                            }
                         }
                     }
                     if (g == 1) {
@@ -550,8 +553,10 @@ __global__ __launch_bounds__(THREADS) void mf_synthesis(SynArgs a) {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int gg = 0; gg < 2; ++gg)
+                            if (!SOLO || wave == gg) {
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) store(gg, j, held[gg][j][0], held[gg][j][1]);
+                                for (int j = 0; j < NJ; ++j) store(gg, j, held[gg][j][0], held[gg][j][1]);
+                            }
                     }
                 }
                 if (xt && wave < G) {  // wave-uniform: item `wave` of this group times the tile kept in LDS
@@ -1010,12 +1015,14 @@ int fbm_lowpass_mfma(const sr_fbm_plan* pl, int dtype, int B, View x, int ups, V
         // k-steps the instance must hold: the coefficient rows and every band's main + window steps
         int need = (nh_real + 15) / 16;
         for (int k = 0; k < 3; ++k) need = std::max(need, pl->mf_ksm[k] + pl->mf_nwin[k]);
-#define SR_SYNH(KS_)                                                                                              \
-    do {                                                                                                          \
-        SR_LDS_ATTR(2 * KS_ * 16 * 256 + WIN_B, mf_synthesis<true, KS_>);                                         \
-        mf_synthesis<true, KS_><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, 2 * KS_ * 16 * 256 + WIN_B, st>>>(s3); \
+#define SR_SYNH(KS_, ...)                                                                                                      \
+    do {                                                                                                                       \
+        SR_LDS_ATTR(2 * KS_ * 16 * 256 + WIN_B, mf_synthesis<true, KS_, ##__VA_ARGS__>);                                       \
+        mf_synthesis<true, KS_, ##__VA_ARGS__><<<grid_for(pl->mf_nw[bfirst], 4), THREADS, 2 * KS_ * 16 * 256 + WIN_B, st>>>(s3); \
     } while (0)
-        if (wide_s) SR_SYNH(17);
+        static const bool no_solo = getenv("SR_AMD_NO_SOLO") != nullptr;  // A/B: the 17th tile by all eight waves
+        if (wide_s && t0 > 0 && t0 + 1 == s3.M / 32 && !no_solo) SR_SYNH(17, true);  // one tile left over: one wave per item
+        else if (wide_s) SR_SYNH(17);
         else if (need <= 4) SR_SYNH(4);
         else if (need <= 8) SR_SYNH(8);
         else SR_SYNH(16);
