@@ -139,7 +139,7 @@ def cpu_baseline(sd, sample_hw, ch=1):
                       'of 3 runs (%.1f s), no extrapolation' % (ch, sample_hw, sample_hw, times[0], dt)}
 
 
-def roofline_fields(prof, prof_all, steps, lr_px_step, ch):
+def roofline_fields(prof, prof_all, steps, lr_px_step, ch, traffic_applies=False):
     """roofline object from the executor's event timings.  prof: conv groups over the timed steps; prof_all: every
     group over one extra untimed step; lr_px_step: LR pixels x samples one step pushes through the network."""
     conv_ms = prof['conv'][0] + prof['head'][0]
@@ -162,6 +162,14 @@ def roofline_fields(prof, prof_all, steps, lr_px_step, ch):
     head_ms = prof_all['head'][0]
     if head_ms > 0:
         groups['head']['tflops'] = 2.0 * conv_macs_per_lr_pixel(ch, ch, head_only=True) * lr_px_step / (head_ms / 1e3) / 1e12
+    hbm_measured = None
+    if traffic_applies and traffic.get('conv'):
+        # the PMC passes profile THIS workload (config 2): bytes per average conv launch / this run's average launch time
+        gbs = traffic['conv'] / 1e9 / (conv_ms / 1e3 / max(conv_n, 1))
+        hbm_measured = {'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                        'note': 'measured HBM traffic of the conv kernels (FETCH_SIZE + WRITE_SIZE per launch) over their '
+                                'launch time: the banded operand (x + three low-pass planes per consumer) makes the '
+                                'kernel HBM-bound on the bytes it has to move, which is why it sits low on the MFMA roof'}
     return {'bound': 'mfma', 'kernel': 'conv3x3_mfma_bf16 (all %d conv launches of a step)' % n_step,
             'achieved': tflops, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / BF16_MFMA_PEAK_TFLOPS,
             'algorithmic_tflop_per_step': flops_step / 1e12, 'avg_launch_ms': conv_ms / max(conv_n, 1),
@@ -171,7 +179,7 @@ def roofline_fields(prof, prof_all, steps, lr_px_step, ch):
                     'algorithmic_gb_per_launch': conv_strict_gb / n_step,
                     'note': 'strict bytes: every conv input once + output once + residual operands; the FDConv operand '
                             'as implemented streams x and three low-pass planes per consumer (4 x cin), see DESIGN.md'},
-            'groups': groups, 'traffic_per_launch_all_groups': traffic}
+            'hbm_measured': hbm_measured, 'groups': groups, 'traffic_per_launch_all_groups': traffic}
 
 
 def run_batch(args, world, rank, dev, dist):
@@ -216,7 +224,7 @@ def run_batch(args, world, rank, dev, dist):
                                'bf16 (BASELINE.json configs[1])' % (B, H, W),
                    'global_batch': world * B, 'parallelism': 'batch-sharded replicas x%d, no exchange' % world,
                    'output_finite': finite},
-        'roofline': roofline_fields(prof, prof_all, args.steps, float(B) * H * W, 1),
+        'roofline': roofline_fields(prof, prof_all, args.steps, float(B) * H * W, 1, traffic_applies=(B, H, W) == (16, 512, 512)),
         'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},
         'kernel_launches_per_step': {k: v[1] for k, v in prof_all.items()},
         'kernel_ms_source': 'one extra untimed step with events around every kernel group; the conv events of the roofline are in the timed steps',
