@@ -139,6 +139,27 @@ def cpu_baseline(sd, sample_hw, ch=1):
                       'of 3 runs (%.1f s), no extrapolation' % (ch, sample_hw, sample_hw, times[0], dt)}
 
 
+def stream_calibration(dev):
+    """What plain streaming kernels reach on this GPU right now (torch's copy and add over 1 GiB tensors): the practical
+    HBM rate next to the 8 TB/s pin rate that `peak` states."""
+    n = 1 << 29
+    x = torch.ones(n, dtype=torch.bfloat16, device=dev)
+    y = torch.empty_like(x)
+    out = {}
+    for name, fn, mult in (('copy_gbs', lambda: y.copy_(x), 2), ('add_gbs', lambda: torch.add(x, y, out=y), 3)):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize(dev)
+        out[name] = mult * n * 2 / 1e9 / ((time.perf_counter() - t0) / 10)
+    del x, y
+    torch.cuda.empty_cache()
+    out['note'] = 'device-to-device copy (1 read + 1 write) and add (2 reads + 1 write) of 1 GiB bf16 tensors, torch kernels'
+    return out
+
+
 def roofline_fields(prof, prof_all, steps, lr_px_step, ch, traffic_applies=False):
     """roofline object from the executor's event timings.  prof: conv groups over the timed steps; prof_all: every
     group over one extra untimed step; lr_px_step: LR pixels x samples one step pushes through the network."""
@@ -229,6 +250,11 @@ def run_batch(args, world, rank, dev, dist):
         'kernel_launches_per_step': {k: v[1] for k, v in prof_all.items()},
         'kernel_ms_source': 'one extra untimed step with events around every kernel group; the conv events of the roofline are in the timed steps',
     }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # after the timed region; skipped in profiling runs
+        try:
+            res['roofline']['stream_calibration'] = stream_calibration(dev)
+        except Exception as e:  # never take the line down
+            res['roofline']['stream_calibration'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(sd, args.cpu_sample, 1)
     return res
