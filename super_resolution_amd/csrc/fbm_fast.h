@@ -157,12 +157,15 @@ template <bool INV> struct Dft<29, INV> : DftOdd<29, INV> {};
 // Radix of the next pass over a remaining length m.  Forward transforms take the power-of-two factors first and the
 // largest odd factor LAST (the outputs of a last pass are contiguous runs of the spectrum: the runs no mask keeps are
 // neither computed nor stored); inverse transforms take the largest odd factor FIRST (the operands of a first pass are
-// contiguous runs of the spectrum: the masked-out runs are not read).  Powers of two: 8, 4, 2 either way.
+// contiguous runs of the spectrum: the masked-out runs are not read).
+// Powers of two: 8, 4, 2 either way.  (Radix 16 where it saves a pass -- 2048 = 8 16 16, 2128 = 19 7 16 -- was measured:
+// the row kernels 6-8 % faster, the column kernels, which also hold the spectrum's first-pass operands, 6-17 % slower at
+// the 128 registers two workgroups per CU leave them; nothing in sum.)
 constexpr int pick_pow2(int m) { return (m % 8 == 0 && m != 16) ? 8 : (m % 4 == 0 ? 4 : 2); }
 template <bool INV>
 constexpr int pick_radix(int m) {
     if (INV) return m % 29 == 0 ? 29 : (m % 19 == 0 ? 19 : (m % 7 == 0 ? 7 : (m % 9 == 0 ? 9 : (m % 3 == 0 ? 3 : pick_pow2(m)))));
-    return m % 2 == 0 ? pick_pow2(m) : (m % 9 == 0 ? 9 : (m % 3 == 0 ? 3 : (m % 7 == 0 ? 7 : (m % 19 == 0 ? 19 : 29))));
+    return m % 2 == 0 ? pick_pow2(m & -m) : (m % 9 == 0 ? 9 : (m % 3 == 0 ? 3 : (m % 7 == 0 ? 7 : (m % 19 == 0 ? 19 : 29))));
 }
 constexpr int first_radix(int n) { return pick_radix<true>(n); }  // of an inverse transform
 
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(THREADS, min_waves(N, PZ)) void rows_inv(View l2, V
         const int a = ak[k];
         const int nk = 2 * a - 1;
         const float2* y = ys[k] + ((long)b * im.NPG * H * nk << im.QL);
+        constexpr int ZMK = band_zm<N, PZ>(k);  // constant-evaluated here, not per thread
 #pragma unroll
         for (int q = 0; q < IT0; ++q) {
             const int i = threadIdx.x + q * THREADS;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(THREADS, min_waves(N, PZ)) void rows_inv(View l2, V
             item_to_pj<P, NR0, BLK>(i, p, j);
 #pragma unroll
             for (int t = 0; t < R0; ++t) {
-                if ((band_zm<N, PZ>(k) >> t) & 1) continue;
+                if ((ZMK >> t) & 1) continue;
                 const int pos = kept_pos<N>(j + t * NR0, a);
                 const bool ok = pos >= 0 && p0 + p < PT && (NB0 % THREADS == 0 || i < NB0);
                 pre[k][q][t] = ok ? y[y_off(im, p0 + p, h, pos, nk, H)] : make_float2(0.f, 0.f);
