@@ -341,6 +341,57 @@ def test_fbm_lowpass_mixed_radix_sizes(L, shape, ups, cb, dt):
     assert (pooled - pooled_gen).abs().max().item() < 1e-6
 
 
+def test_fbm_lowpass_mixed_radix_full_width_properties(L):
+    """The same kernels at the width the tiled configuration runs them (64 channels = 32 pairs = 8 pair groups per row
+    block, batch 2, 2128 x 2088, bf16, channel-blocked): too large for the oracle in test time, so the check is through
+    properties -- plane sums (the DC bin) equal the mean, every band keeps the mean, the bands are nested
+    (L4(L2 x) = L4 x, L8(L4 x) = L8 x up to the bf16 rounding of the intermediate plane) -- and against the generic FFT."""
+    lib = L.lib()
+    B, Cc, H, W = 2, 64, 2128, 2088
+    g = torch.Generator(device='cuda:0').manual_seed(5)
+    x = (torch.rand(B, Cc // 8, H, W, 8, device='cuda:0', generator=g) - 0.3).to(torch.bfloat16)
+
+    def run(src):
+        plan = C.c_void_p()
+        L.check(lib.sr_fbm_plan_create(H, W, C.byref(plan)))
+        bands = [torch.full((B, Cc // 8, H, W, 8), float('nan'), device='cuda:0', dtype=torch.bfloat16) for _ in range(3)]
+        pooled = torch.full((B, Cc), float('nan'), device='cuda:0')
+        ws = torch.empty(lib.sr_fbm_workspace_bytes(plan, B, Cc), dtype=torch.uint8, device='cuda:0')
+        L.check(lib.sr_fbm_lowpass(plan, L.dtype_code(torch.bfloat16), B, L.blocked_view(src), 0, L.blocked_view(bands[0]),
+                                   L.blocked_view(bands[1]), L.blocked_view(bands[2]), pooled.data_ptr(), Cc, ws.data_ptr(),
+                                   ws.numel(), st(L)))
+        torch.cuda.synchronize()
+        path = lib.sr_debug_last_lowpass_path()
+        lib.sr_fbm_plan_destroy(plan)
+        return bands, pooled, path
+
+    chan_mean = lambda t: t.float().mean(dim=(2, 3)).permute(0, 1, 2).reshape(B, Cc)  # noqa: E731  (B, C/8, 8) -> (B, C)
+    lib.sr_debug_force_fft_lowpass(1)
+    try:
+        bands, pooled, path = run(x)
+        assert path == 2, path
+        again2, _, _ = run(bands[0])
+        again4, _, _ = run(bands[1])
+        lib.sr_debug_no_mixed_fft(1)
+        try:
+            gen, pooled_gen, path_gen = run(x)
+        finally:
+            lib.sr_debug_no_mixed_fft(0)
+        assert path_gen == 0
+    finally:
+        lib.sr_debug_force_fft_lowpass(-1)
+    mean = chan_mean(x)
+    assert (pooled - mean).abs().max().item() < 1e-4
+    assert (pooled - pooled_gen).abs().max().item() < 1e-6
+    for k in range(3):
+        assert torch.isfinite(bands[k].float()).all()
+        assert (chan_mean(bands[k]) - mean).abs().max().item() < 2e-3, k   # bf16 rounding of 4.4 M samples averages out
+        assert (bands[k].float() - gen[k].float()).abs().max().item() <= 2.0 ** -7, k
+    assert (again2[1].float() - bands[1].float()).abs().max().item() <= 2.0 ** -6   # L4(L2 x) = L4 x
+    assert (again2[2].float() - bands[2].float()).abs().max().item() <= 2.0 ** -6   # L8(L2 x) = L8 x
+    assert (again4[2].float() - bands[2].float()).abs().max().item() <= 2.0 ** -6   # L8(L4 x) = L8 x
+
+
 def test_fbm_lowpass_upsampled_and_bf16(L):
     x = torch.from_numpy(gp.signed_input((2, 8, 20, 24), 12))
     xu = F.interpolate(x, scale_factor=2, mode='nearest')
