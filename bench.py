@@ -535,7 +535,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=128, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
     ap.add_argument('--no-secondary', action='store_true', help='batch: skip the one-step runs of the tiled / train / srvgg configs (N > 1: tiled and train, sharded over the ranks)')
-    ap.add_argument('--secondary-deadline', type=int, default=420, help='batch: seconds the secondary configs may take before the headline is printed without them')
+    ap.add_argument('--secondary-deadline', type=int, default=300, help='batch: seconds the secondary configs may take before the headline is printed without them')
     ap.add_argument('--no-split-weights', action='store_true', help='A/B: plain bf16 dynamic weights instead of hi + lo pairs')
     args = ap.parse_args()
 
