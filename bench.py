@@ -266,7 +266,7 @@ def run_tiled(args, world, rank, dev, dist):
     side = args.image
     img = (np.random.default_rng(1234).random((side, side, 3)) * 255).astype(np.uint8)
     r = RealESRGANer(scale=4, model_path=None, model=net, tile=args.tile, tile_pad=args.tile_pad, pre_pad=0, half=True,
-                     device=dev, shard_tiles=True, tile_batch=args.tile_batch)
+                     device=dev, shard_tiles=True, tile_batch=args.tile_batch or None)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -358,7 +358,7 @@ def run_tiled(args, world, rank, dev, dist):
         'config': {'workload': 'RealESRGANer(tile=%d, tile_pad=%d, pre_pad=0, half=True) x4 on one %dx%d synthetic RGB image, '
                                '%s, bf16 (BASELINE.json configs[2])' % (args.tile, args.tile_pad, side, side,
                                                                        'plain RRDBNet(3,3,64,23,32) = RealESRGAN_x4plus architecture (configs[0] network)' if args.plain else 'RRDBNet-FDConv(3,3,64,23,32)'),
-                   'tiles': len(wins), 'tile_batch': args.tile_batch,
+                   'tiles': len(wins), 'tile_batch': r.tile_batch, 'tile_batch_automatic': not args.tile_batch,
                    'parallelism': '%d tiles sorted by window shape, one contiguous block per rank over %d rank(s), one p2p message per peer (its cores stacked in shard order) to rank 0, no collective' % (len(wins), world),
                    'timed_region': 'tile_process() + post_process() with the padded image resident in HBM; max over ranks incl. the gather',
                    'enhance_host_to_host_s': t_enh, 'enhance_host_to_host_out_mpix_s': out_mpix / t_enh,
@@ -531,7 +531,7 @@ def main():
     ap.add_argument('--plain', action='store_true', help='tiled: the plain RRDBNet (RealESRGAN_x4plus architecture, BASELINE configs[0] network) instead of RRDBNet-FDConv')
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--tile-pad', type=int, default=10)
-    ap.add_argument('--tile-batch', type=int, default=18, help='tiled: tiles of equal window size per forward (8 -> 18: 45.7 -> 49.2 out-Mpix/s at N = 1)')
+    ap.add_argument('--tile-batch', type=int, default=18, help='tiled: tiles of equal window size per forward (8 -> 18: 45.7 -> 49.2 out-Mpix/s at N = 1); 0 = left to RealESRGANer (its default: sized from the free device memory, at most 18)')
     ap.add_argument('--cpu-sample', type=int, default=128, help='side of the CPU-baseline sample image (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU-baseline leg (profiling runs)')
     ap.add_argument('--no-secondary', action='store_true', help='batch: skip the one-step runs of the tiled / train / srvgg configs (N > 1: tiled and train, sharded over the ranks)')

@@ -134,6 +134,25 @@ class RRDBNet(nn.Module):
         st = self._state(dt, x.device)
         return st.forward(x.contiguous(), io_dt)
 
+    def workspace_bytes(self, B, H, W, dtype=torch.float32):
+        """Executor workspace an inference forward of (B, C, H, W) needs, in bytes (0: cannot be sized).  `dtype`: the
+        input's dtype (compute_dtype overrides it, as in forward).  RealESRGANer sizes its automatic tile batch with it."""
+        dt = self.compute_dtype or dtype
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('RRDBNet.workspace_bytes: the network must be on the GPU')
+        st = self._state(dt, dev)
+        lib = L.lib()
+        with torch.cuda.device(dev):
+            if (H, W) not in st.prepared:
+                L.check(lib.sr_rrdbnet_prepare(st.h, H, W), 'sr_rrdbnet_prepare')
+                st.prepared.add((H, W))
+            return int(lib.sr_rrdbnet_workspace_bytes(st.h, L.dtype_code(dt), B, H, W))
+
+    def workspace_held(self):
+        """Bytes of workspace the executor holds already (re-used by forwards that need no more)."""
+        return 0 if self._sr is None or self._sr.ws is None else int(self._sr.ws.numel())
+
     def profile(self, enable=True):
         """Per-kernel-group HIP-event timing of the next forward (bench.py)."""
         if self._sr is None:

@@ -421,6 +421,37 @@ def test_tile_batching_with_dynamic_weights(sra):
     assert (outs[0][:, :, y0 * 4:y1 * 4, x0 * 4:x1 * 4] - ref).abs().max().item() < FP32_TOL
 
 
+def test_automatic_tile_batch_equals_one_by_one_and_respects_memory(sra, monkeypatch):
+    """tile_batch left to the library (the default): the batch is sized from the executor's workspace formula and the free
+    device memory, the image is bit for bit the one-tile-at-a-time image, and with no memory to claim it falls back to 1."""
+    sd = t(gp.rrdbnet_state(3, 3, 64, 1, 32, seed=33))
+    img = gp.image_input((200, 248, 3), 98)   # 5 x 6 tiles of 48: 3 x 4 interior windows of 64 x 64
+
+    def run(**kw):
+        net = sra.replace_conv_with_fdconv(sra.RRDBNet(3, 3, 4, 64, 1, 32))
+        net.load_state_dict(sd, strict=True)
+        r = sra.RealESRGANer(scale=4, model_path=None, model=net, tile=48, tile_pad=8, pre_pad=0, half=True, **kw)
+        r.pre_process(img)
+        r.tile_process()
+        return r, r.post_process().float().cpu()
+
+    r_auto, auto = run()
+    assert r_auto._tile_batch_arg is None and r_auto.tile_batch == 12, r_auto.tile_batch   # all tiles of the commonest shape
+    r_one, one = run(tile_batch=1)
+    assert r_one.tile_batch == 1
+    assert torch.equal(auto, one)
+    # the workspace of the chosen batch was what the formula said, and it was within the budget
+    need = r_auto.model.workspace_bytes(12, 64, 64, torch.float32)
+    assert 0 < need <= r_auto.model.workspace_held()
+    monkeypatch.setattr(sra.RealESRGANer, 'AUTO_TILE_BATCH_MEMORY', 1e-9)
+    r_tight, tight = run()
+    assert r_tight.tile_batch == 1 and torch.equal(tight, one)
+    monkeypatch.setattr(sra.RealESRGANer, 'AUTO_TILE_BATCH_MEMORY', 0.5)
+    monkeypatch.setattr(sra.RealESRGANer, 'AUTO_TILE_BATCH_CAP', 4)
+    r_cap, capped = run()
+    assert r_cap.tile_batch == 4 and torch.equal(capped, one)
+
+
 def test_train_mode_forward_records_an_autograd_graph(sra):
     """a train()-mode forward must never hand back a tensor without grad_fn (tests/test_gpu_train.py
     checks the gradients themselves)."""
