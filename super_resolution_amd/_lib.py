@@ -129,6 +129,7 @@ _SIGS = {
     'sr_debug_force_generic_conv': (None, [C.c_int]),
     'sr_debug_force_generic_fft': (None, [C.c_int]),
     'sr_debug_no_mixed_fft': (None, [C.c_int]),
+    'sr_debug_operand_f16': (None, [C.c_int]),
     'sr_debug_last_lowpass_path': (C.c_int, []),
     'sr_debug_force_fft_lowpass': (None, [C.c_int]),
     'sr_debug_no_ups_shortcut': (None, [C.c_int]),

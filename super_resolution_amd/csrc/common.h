@@ -113,6 +113,34 @@ __device__ __forceinline__ uint32_t modulate2(uint32_t x, uint32_t a, uint32_t b
     r = __builtin_elementwise_fma(c3, unpack2(c), r);
     return pack2(r.x, r.y);
 }
+// fp16 operands (opt-in, DESIGN.md finding 39): the same mix packed to fp16 (v_cvt_pk_f16_f32, round to nearest even; values
+// beyond +-65504 become +-inf as in any fp16 evaluation)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+    const half2v h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+template <bool F16>
+__device__ __forceinline__ uint32_t modulate2t(uint32_t x, uint32_t a, uint32_t b, uint32_t c, float2v c0, float2v c1, float2v c2,
+                                               float2v c3) {
+    float2v r = c0 * unpack2(x);
+    r = __builtin_elementwise_fma(c1, unpack2(a), r);
+    r = __builtin_elementwise_fma(c2, unpack2(b), r);
+    r = __builtin_elementwise_fma(c3, unpack2(c), r);
+    return F16 ? pack2h(r.x, r.y) : pack2(r.x, r.y);
+}
+template <bool F16>
+__device__ __forceinline__ uint4 modulate8t(uint4 x, uint4 a, uint4 b, uint4 c, float c0, float c1, float c2, float c3) {
+    const float2v k0 = {c0, c0}, k1 = {c1, c1}, k2 = {c2, c2}, k3 = {c3, c3};
+    uint4 r;
+    r.x = modulate2t<F16>(x.x, a.x, b.x, c.x, k0, k1, k2, k3);
+    r.y = modulate2t<F16>(x.y, a.y, b.y, c.y, k0, k1, k2, k3);
+    r.z = modulate2t<F16>(x.z, a.z, b.z, c.z, k0, k1, k2, k3);
+    r.w = modulate2t<F16>(x.w, a.w, b.w, c.w, k0, k1, k2, k3);
+    return r;
+}
 __device__ __forceinline__ uint4 modulate8(uint4 x, uint4 a, uint4 b, uint4 c, float c0, float c1, float c2, float c3) {
     const float2v k0 = {c0, c0}, k1 = {c1, c1}, k2 = {c2, c2}, k3 = {c3, c3};
     uint4 r;
@@ -208,8 +236,10 @@ inline Epilogue to_epilogue(const sr_epilogue* e, long npix) {
 
 // internal launchers shared with the network executor (same semantics as the extern "C" entry points)
 // w_lo_off != 0 (bf16 MFMA kernel only): weights + w_lo_off holds the low-order bf16 parts of the same weights
+// w_lo_off == SR_WLO_F16: fp16 weights + fp16 operand (see below); only where conv3x3_f16_ok() holds
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* weights,
                    long w_bstride, long w_lo_off, int cout, const Epilogue& ep, View out, hipStream_t st);
+bool conv3x3_f16_ok(int dtype, const Concat& in, const void* weights, long w_bstride, int cout, const Epilogue& ep, View out);
 
 // bmask: bit k set = band k (l2 / l4 / l8) is wanted; views of unwanted bands are never written (callers pass a copy of a
 // wanted one so that the layout checks see a valid view)
@@ -244,6 +274,9 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
 // mods: weightgen_ws_bytes(B, cin, cout) of scratch (the modulation vectors ca | ln | fa | sa | ka per sample stay there);
 // train: BatchNorm on batch statistics, lp.bn_rm / lp.bn_rv updated in place with `momentum`
 size_t weightgen_ws_bytes(int B, int cin, int cout);
+// wdyn_lo == SR_WDYN_F16 (bf16 only): wdyn receives ONE fp16 value per weight instead of a bf16 hi (+ lo) pair
+#define SR_WDYN_F16 ((void*)(intptr_t)-1)
+#define SR_WLO_F16 (-1L)   // conv3x3_launch: w_lo_offset value that says "weights are fp16, pack the banded operand to fp16"
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, int train, float momentum,
                      void* wdyn, void* wdyn_lo, float* mods, hipStream_t st);
 

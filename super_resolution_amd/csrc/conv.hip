@@ -238,7 +238,9 @@ __device__ __forceinline__ TileId decode_tile(unsigned lin, unsigned tiles, int 
 // per workgroup instead of once per tile and chunk -- for a plain layer the slab is as many bytes as the chunk's pixels --
 // and no chunk barrier has to drain the MFMA waves' vector-memory counter any more, so the epilogue's stores retire
 // behind the next tile's multiplies.
-template <int MT, bool BANDS, int SPLIT, bool RES = false>
+// F16 (BANDS, SPLIT = 0; opt-in, DESIGN.md finding 39): the weights are ONE fp16 value each, the loader packs the mixed operand to
+// fp16 and the multiply is v_mfma_f32_32x32x16_f16 -- the instruction, slab and fragment counts of unsplit weights.
+template <int MT, bool BANDS, int SPLIT, bool RES = false, bool F16 = false>
 __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H, int W, const float* __restrict__ gates,
                                                          const bf16_t* __restrict__ wts, long w_bstride, long w_lo_off,
                                                          int cin, int cout, Epilogue ep, View out, unsigned total, int wmap) {
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int g = 0; g < G; ++g) {
                 const int k = r * G + g;
                 uint4 v = bt.vx[g];
-                if (BANDS) v = modulate8(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
+                if (BANDS) v = modulate8t<F16>(v, bt.a2[g], bt.a4[g], bt.a8[g], bt.gg[g].x, bt.gg[g].y - bt.gg[g].x, bt.gg[g].z - bt.gg[g].y, 1.0f - bt.gg[g].z);
                 if (!((inside >> k) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                 if ((k + 1) * 256 <= NPIX * 4 || ltid + k * 256 < NPIX * 4) *(uint4*)(lds_px + (it_lds[k] & 0xffffu)) = v;
             }
@@ -519,7 +521,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
+                    if constexpr (F16)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8v, f.a[m]), __builtin_bit_cast(half8v, f.b[n]), acc[m][n], 0, 0, 0);
+                    else
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
                     if (SPLIT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a2[m], f.b[n], acc[m][n], 0, 0, 0);
                 }
         };
@@ -704,20 +709,22 @@ static bool mfma_eligible(const Concat& in, int cout, const Epilogue& ep, const 
     return true;
 }
 
-template <int MT, bool BANDS, int SPLIT, bool RES = false>
+template <int MT, bool BANDS, int SPLIT, bool RES = false, bool F16 = false>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
     const size_t nslab = RES ? (size_t)(in.ctot / 32) : (SPLIT == 2 ? 4 : 2);
     const size_t ldsb = 2 * (size_t)NPIX * 64 + nslab * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
     if (RES && (wbs != 0 || wlo != 0 || cdiv(cout, MT * 32) != 1)) return SR_NOT_ELIGIBLE;
-    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT, RES>);  // per device
+    static_assert(!F16 || (BANDS && SPLIT == 0 && !RES), "fp16 operands: banded layers with single weights");
+    if (F16) wlo = 0;  // the marker, not an offset
+    SR_LDS_ATTR(ldsb, conv3x3_mfma_bf16<MT, BANDS, SPLIT, RES, F16>);  // per device
     const long nblk = (long)cdiv(H, MTH) * cdiv(W, MTW) * B * cdiv(cout, MT * 32);
     if (nblk >= (1L << 31)) return SR_ERR_ARG;
     int ncu = 0;  // persistent workgroups: one per CU (the two LDS stages fill a CU's LDS)
     if (int rc = device_cus(&ncu)) return rc;
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-    conv3x3_mfma_bf16<MT, BANDS, SPLIT, RES><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk, g_split_two_pass);
+    conv3x3_mfma_bf16<MT, BANDS, SPLIT, RES, F16><<<dim3(grid), 512, ldsb, st>>>(in, B, H, W, gates, (const bf16_t*)wts, wbs, wlo, in.ctot, cout, ep, out, (unsigned)nblk, g_split_two_pass);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }
@@ -725,8 +732,17 @@ static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates
 int g_force_generic = 0;  // test hook: route bf16 through the VALU kernel
 int g_no_resident = 0;    // test hook (A/B): shared weights streamed per chunk like per-sample ones
 
+bool conv3x3_f16_ok(int dtype, const Concat& in, const void* wts, long wbs, int cout, const Epilogue& ep, View out) {
+    return dtype == SR_BF16 && in.bands && !g_force_generic && mfma_eligible(in, cout, ep, out, wts, wbs);
+}
+
 int conv3x3_launch(int dtype, int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs,
                    long wlo, int cout, const Epilogue& ep, View out, hipStream_t st) {
+    if (wlo == SR_WLO_F16) {  // one fp16 weight per MAC, operand packed to fp16 by the band-mixing loader: matrix-core kernel only
+        if (dtype != SR_BF16 || !in.bands || g_force_generic || !mfma_eligible(in, cout, ep, out, wts, wbs)) return SR_ERR_ARG;
+        return cout % 64 == 0 ? launch_mfma<2, true, 0, false, true>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st)
+                              : launch_mfma<1, true, 0, false, true>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
+    }
     if (dtype == SR_F32) return launch_generic<float>(B, H, W, in, gates, wts, wbs, wlo, cout, ep, out, st);
     if (!g_force_generic && mfma_eligible(in, cout, ep, out, wts, wbs)) {
         const bool two = (cout % 64 == 0);

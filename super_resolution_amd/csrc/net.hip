@@ -82,6 +82,9 @@ namespace {
 
 // profile groups: head = conv_up1 / conv_up2 / conv_hr / conv_last (the 2x / 4x resolution convs), lowpass_hr = their low-pass launches
 int g_split_weights = 1;  // bf16: dynamic weights as hi + lo pairs (test hook sr_debug_split_weights)
+// opt-in (SR_AMD_OPERAND_F16=1 or sr_debug_operand_f16): the FDConv layers' matrix-core operands in fp16 -- ONE fp16 weight per MAC
+// instead of the bf16 pair, the band-mixed activations packed to fp16 by the loader (DESIGN.md finding 39)
+int g_operand_f16 = getenv("SR_AMD_OPERAND_F16") != nullptr && atoi(getenv("SR_AMD_OPERAND_F16")) != 0;
 int g_graphs_on = getenv("SR_AMD_GRAPH") && atoi(getenv("SR_AMD_GRAPH")) != 0;
 
 enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4, G_HEAD = 5, G_LOWPASS_HR = 6, G_NGROUPS = 8 };
@@ -238,9 +241,10 @@ struct Run {
             hipStream_t wgs = fork ? net->side : st;
             if (fork && (hipEventRecord(net->ev_fork, st) != hipSuccess || hipStreamWaitEvent(net->side, net->ev_fork, 0) != hipSuccess)) { rc = SR_ERR_HIP; return; }
             prof_begin(G_WGEN, wgs);
-            const long wlo = dtype == SR_BF16 && g_split_weights ? (long)B * 9 * lp.cout * lp.cin : 0;  // elements from hi to lo
+            const bool f16 = g_operand_f16 && conv3x3_f16_ok(dtype, c, ws + L.wdyn, 9L * lp.cout * lp.cin, lp.cout, ep, out);
+            const long wlo = f16 ? SR_WLO_F16 : (dtype == SR_BF16 && g_split_weights ? (long)B * 9 * lp.cout * lp.cin : 0);  // elements from hi to lo
             rc = weightgen_launch(dtype, B, (const float*)(ws + L.pooled), net->nf + 4 * net->gc, lp, 0, 0.f, ws + L.wdyn,
-                                  wlo ? ws + L.wdyn + (size_t)wlo * es : nullptr, (float*)(ws + L.mods), wgs);
+                                  f16 ? SR_WDYN_F16 : (wlo ? ws + L.wdyn + (size_t)wlo * es : nullptr), (float*)(ws + L.mods), wgs);
             prof_end(wgs);
             if (rc != SR_OK) return;
             if (fork && hipEventRecord(net->ev_join, net->side) != hipSuccess) { rc = SR_ERR_HIP; return; }
@@ -623,3 +627,4 @@ extern "C" int sr_rrdbnet_profile_read(sr_rrdbnet* n, float* ms8, long* launches
 
 // test hook (A/B): 0 = plain bf16 dynamic weights, 1 = hi + lo pairs (default)
 extern "C" void sr_debug_split_weights(int on) { g_split_weights = on; }
+extern "C" void sr_debug_operand_f16(int on) { g_operand_f16 = on; }

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(1024) void ksm_kernel(const float* __restrict__ poo
 
 template <typename T>
 __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ mods, sr_layer_params lp, T* __restrict__ wdyn,
-                                                        T* __restrict__ wdyn_lo) {
+                                                        T* __restrict__ wdyn_lo, int f16 = 0) {
     const int cin = lp.cin, cout = lp.cout, taps = lp.loc_taps, pad = (taps - 1) / 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= cout * cin) return;
@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
         const float hr = 2.0f * sigmoidf(logit);
         const float w = sa[tap] * cf * ad[tap] * hr;
         const long at = b * bstride + ((long)tap * cout + o) * cin + ci;
+        if (sizeof(T) == 2 && f16) {  // one fp16 value per weight (opt-in operand format of the banded conv)
+            ((uint16_t*)wdyn)[at] = f32_to_f16_bits(w);
+            continue;
+        }
         Elem<T>::st(wdyn + at, w);
         if (wdyn_lo) Elem<T>::st(wdyn_lo + at, w - Elem<T>::ld(wdyn + at));  // w = hi + lo, both in T (bf16: 16 significant bits)
     }
@@ -256,6 +260,7 @@ size_t weightgen_ws_bytes(int B, int cin, int cout) { return align_up((size_t)B 
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, int train, float momentum,
                      void* wdyn, void* wdyn_lo, float* mods, hipStream_t st) {
     if (lp.loc_taps > 15) return SR_ERR_ARG;
+    if (wdyn_lo == SR_WDYN_F16 && dtype != SR_BF16) return SR_ERR_ARG;
     if (train && (B < 2 || B > KSM_MAX_B)) return SR_ERR_ARG;  // BatchNorm needs more than one value per channel
     if (train) {
         size_t sh = ((size_t)B * ATT + 2 * ATT) * sizeof(float);
@@ -272,7 +277,8 @@ int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const
     if (dtype == SR_F32)
         aggregate_kernel<float><<<grid, 256, 0, st>>>(mods, lp, (float*)wdyn, (float*)wdyn_lo);
     else
-        aggregate_kernel<bf16_t><<<grid, 256, 0, st>>>(mods, lp, (bf16_t*)wdyn, (bf16_t*)wdyn_lo);
+        if (wdyn_lo == SR_WDYN_F16) aggregate_kernel<bf16_t><<<grid, 256, 0, st>>>(mods, lp, (bf16_t*)wdyn, nullptr, 1);
+        else aggregate_kernel<bf16_t><<<grid, 256, 0, st>>>(mods, lp, (bf16_t*)wdyn, (bf16_t*)wdyn_lo);
     SR_LAUNCH_CHECK();
     return SR_OK;
 }

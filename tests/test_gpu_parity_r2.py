@@ -143,6 +143,59 @@ def test_23_blocks_bf16_psnr_delta_realistic_weights(sra):
     assert d_gpu > d_emu - 3.0
 
 
+def test_fp16_operand_mode_holds_the_psnr_budget(sra, capfd):
+    """Opt-in operand format (sr_debug_operand_f16 / SR_AMD_OPERAND_F16=1; DESIGN.md finding 39): the FDConv layers multiply
+    ONE fp16 weight per MAC with an operand the loader packs to fp16, instead of a bf16 hi + lo pair with a bf16 operand.
+    north_star's criterion (PSNR delta <= 0.05 dB) on the budget test's ill-conditioned 64 x 64 pair and on the 512 x 512
+    fixture pair, the distance from the default path, and that the mode really is a different kernel (outputs differ)."""
+    from super_resolution_amd import _lib
+    import make_golden_r3 as mg3
+    lib = _lib.lib()
+
+    def both(net, x):
+        with torch.no_grad():
+            y_def = net(x.cuda().to(torch.bfloat16)).float().cpu()
+            lib.sr_debug_operand_f16(1)
+            try:
+                y_f16 = net(x.cuda().to(torch.bfloat16)).float().cpu()
+            finally:
+                lib.sr_debug_operand_f16(0)
+        return y_def, y_f16
+
+    net, sd = realistic_net(sra, (1, 1, 4, 64, 23, 32), seed=2)
+    x = torch.from_numpy(gp.image_input((1, 1, 64, 64), 83))
+    with torch.no_grad():
+        ref = rrdbnet_forward(sd, x)
+    y_def, y_f16 = both(net, x)
+    assert torch.isfinite(y_f16).all() and not torch.equal(y_def, y_f16)
+    target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
+    lo, hi = ref.min(), ref.max()
+    n = lambda v: (v - lo) / (hi - lo)  # noqa: E731
+    p_ref = psnr(n(ref).clamp(0, 1), target)
+    d64 = abs(psnr(n(y_f16).clamp(0, 1), target) - p_ref)
+    print('fp16 operands, 23 blocks 64x64: PSNR delta %.4f dB (default path %.4f dB); direct vs fp32 oracle %.1f dB (default %.1f dB)'
+          % (d64, abs(psnr(n(y_def).clamp(0, 1), target) - p_ref), psnr(n(y_f16), n(ref)), psnr(n(y_def), n(ref))))
+    assert d64 <= PSNR_DELTA_DB
+    assert psnr(n(y_f16), n(ref)) > 40.0
+
+    x = torch.from_numpy(gp.image_input((1, 1, 512, 512), 84))
+    y_def, y_f16 = both(net, x)
+    o = _oracle_512(sd, x, capfd)
+    lo, hi = o['ref32_min'], o['ref32_max']
+    n = lambda v: (v - lo) / (hi - lo)  # noqa: E731
+    a, b = mg3.CROP
+    pick = lambda v: torch.cat([v[0, 0, ::mg3.STRIDE, ::mg3.STRIDE].reshape(-1), v[0, 0, a:b, a:b].reshape(-1)])  # noqa: E731
+    ref = torch.cat([o['ref32_lattice'].reshape(-1), o['ref32_crop'].reshape(-1)]).float()
+    target = pick(torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1))
+    p_ref = psnr(n(ref).clamp(0, 1), target)
+    d512 = abs(psnr(n(pick(y_f16)).clamp(0, 1), target) - p_ref)
+    print('fp16 operands, 23 blocks 512x512: PSNR delta %.4f dB (default path %.4f dB); direct vs fp32 oracle %.1f dB (default %.1f dB)'
+          % (d512, abs(psnr(n(pick(y_def)).clamp(0, 1), target) - p_ref), psnr(n(pick(y_f16)), n(ref)), psnr(n(pick(y_def)), n(ref))))
+    assert torch.isfinite(y_f16).all()
+    assert d512 <= PSNR_DELTA_DB
+    assert psnr(n(pick(y_f16)), n(ref)) > 40.0
+
+
 class _Heartbeat:
     """A dot on the REAL stdout every 30 s while a long CPU oracle runs (the GPU box's watchdog ends a command that
     prints nothing for three minutes; pytest holds captured output back until the test ends)."""
