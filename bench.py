@@ -619,8 +619,9 @@ def main():
                                           'wall_s': time.perf_counter() - t0}
                 if f16:
                     res['secondary'][name]['note'] = ('opt-in (SR_AMD_OPERAND_F16=1): one fp16 weight per MAC and an fp16 operand in the FDConv '
-                                                      'convs instead of bf16 hi + lo weights; PSNR delta 0.046 dB on the budget test\'s 64x64 pair, '
-                                                      '0.007 dB at 512x512 (tests/test_gpu_parity_r2.py); NOT the default, not the headline')
+                                                      'convs instead of bf16 hi + lo weights, plus a tenth weight plane (the summed rounding remainders on the centre tap); '
+                                                      'PSNR delta 0.008 dB on the budget test\'s 64x64 pair, 0.007 dB at 512x512 (tests/test_gpu_parity_r2.py), '
+                                                      'worse than the default on one borderline seed of twelve (profiles/r03_k_f16_pairs.txt); NOT the default, not the headline')
             except Exception as e:  # a secondary config must never take the headline line down with it
                 res['secondary'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
                 if world > 1:  # the peers may already be inside the next collective: do not join them half-way

@@ -274,7 +274,8 @@ int fbm_gates_acc_launch(int B, int H, int W, View seg, const GateConsList& cl, 
 // mods: weightgen_ws_bytes(B, cin, cout) of scratch (the modulation vectors ca | ln | fa | sa | ka per sample stay there);
 // train: BatchNorm on batch statistics, lp.bn_rm / lp.bn_rv updated in place with `momentum`
 size_t weightgen_ws_bytes(int B, int cin, int cout);
-// wdyn_lo == SR_WDYN_F16 (bf16 only): wdyn receives ONE fp16 value per weight instead of a bf16 hi (+ lo) pair
+// wdyn_lo == SR_WDYN_F16 (bf16 only): wdyn receives ONE fp16 value per weight instead of a bf16 hi (+ lo) pair, as [B][10][cout][cin]:
+// plane 9 holds the 9-tap sums of the rounding remainders (needs 10/9 of the single-weight buffer: the split layout's 2x covers it)
 #define SR_WDYN_F16 ((void*)(intptr_t)-1)
 #define SR_WLO_F16 (-1L)   // conv3x3_launch: w_lo_offset value that says "weights are fp16, pack the banded operand to fp16"
 int weightgen_launch(int dtype, int B, const float* pooled, int pooled_ld, const sr_layer_params& lp, int train, float momentum,

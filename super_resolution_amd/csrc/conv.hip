@@ -246,7 +246,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                                                          int cin, int cout, Epilogue ep, View out, unsigned total, int wmap) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int STAGE_PX = NPIX * 64;
-    constexpr int WSLAB = 9 * MT * 32 * 64;
+    // F16: a tenth weight plane per chunk -- the 9-tap SUM of what rounding the weights to fp16 lost -- multiplies the centre pixel
+    // once more: the part of the rounding error that is coherent over the image (a gain error of the layer) is taken out for a
+    // ninth of the second pass a hi + lo pair costs (DESIGN.md finding 39)
+    constexpr int TAPS = F16 ? 10 : 9;
+    constexpr int WSLAB = TAPS * MT * 32 * 64;
     char* const lds_wa = lds + 2 * STAGE_PX;
     char* const lds_wb = lds_wa + WSLAB;
     const int tilesx = (W + MTW - 1) / MTW;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
     // which holds channel group (l & 3) ^ ((row >> 2) & 3).  Rows of a thin layer beyond cout repeat the last row: an
     // output row depends on its own weight row only and the epilogue never stores those rows.
     auto slab_dma = [&](int sb, int so_blk, int skc, long part_off, char* lds_slab) {
-        constexpr int NI = 9 * MT * 32 / 16;  // 1 KiB pieces per slab
+        constexpr int NI = TAPS * MT * 32 / 16;  // 1 KiB pieces per slab
         const bf16_t* base = wts + (long)sb * w_bstride + part_off;
 #pragma unroll
         for (int jj = 0; jj < (NI + 3) / 4; ++jj) {
@@ -501,8 +505,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         struct Frags {
             short8 a[MT], a2[MT], b[4];
         };
-        auto load_step = [&](int dy, int dx, int kk, Frags& f, const char* cur_px, const char* cur_w, const char* cur_w2) {
-            const int tap = dy * 3 + dx;
+        auto load_step_tap = [&](int tap, int dy, int dx, int kk, Frags& f, const char* cur_px, const char* cur_w, const char* cur_w2) {
             const int chunk = kk * 2 + hk;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -515,6 +518,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 const int pi = (wave * 4 + n + dy) * PW + r + dx;
                 f.b[n] = *(const short8*)(cur_px + swz(pi, chunk));
             }
+        };
+        auto load_step = [&](int dy, int dx, int kk, Frags& f, const char* cur_px, const char* cur_w, const char* cur_w2) {
+            load_step_tap(dy * 3 + dx, dy, dx, kk, f, cur_px, cur_w, cur_w2);
         };
         auto mfma_step = [&](const Frags& f) {
 #pragma unroll
@@ -546,6 +552,12 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
                 load_step(dy, 2, 1, f1, cur_px, cur_w, cur_w2);
                 mfma_step(f0);
                 load_step(dy < 2 ? dy + 1 : 2, 0, 0, f0, cur_px, cur_w, cur_w2);  // last round: a harmless re-read, no branch
+                mfma_step(f1);
+            }
+            if constexpr (F16) {  // plane 9 (the summed rounding remainders) times the centre pixel
+                load_step_tap(9, 1, 1, 0, f0, cur_px, cur_w, cur_w2);
+                load_step_tap(9, 1, 1, 1, f1, cur_px, cur_w, cur_w2);
+                mfma_step(f0);
                 mfma_step(f1);
             }
         };
@@ -713,7 +725,7 @@ template <int MT, bool BANDS, int SPLIT, bool RES = false, bool F16 = false>
 static int launch_mfma(int B, int H, int W, const Concat& in, const float* gates, const void* wts, long wbs, long wlo, int cout,
                        const Epilogue& ep, View out, hipStream_t st) {
     const size_t nslab = RES ? (size_t)(in.ctot / 32) : (SPLIT == 2 ? 4 : 2);
-    const size_t ldsb = 2 * (size_t)NPIX * 64 + nslab * 9ul * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
+    const size_t ldsb = 2 * (size_t)NPIX * 64 + nslab * (F16 ? 10ul : 9ul) * MT * 32 * 64 + 2 * (size_t)cout * sizeof(float);  // stages + slabs + bias + slopes
     if (ldsb > 160 * 1024) return SR_NOT_ELIGIBLE;
     if (RES && (wbs != 0 || wlo != 0 || cdiv(cout, MT * 32) != 1)) return SR_NOT_ELIGIBLE;
     static_assert(!F16 || (BANDS && SPLIT == 0 && !RES), "fp16 operands: banded layers with single weights");

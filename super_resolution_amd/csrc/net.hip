@@ -278,7 +278,7 @@ struct Run {
             if (rc != SR_OK) return;
             if (fork && hipStreamWaitEvent(st, net->ev_join, 0) != hipSuccess) { rc = SR_ERR_HIP; return; }
             prof_begin(head ? G_HEAD : G_CONV);
-            rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, 9L * lp.cout * lp.cin, wlo, lp.cout, ep, out, st);
+            rc = conv3x3_launch(dtype, B, Hc, Wc, c, gates, ws + L.wdyn, (f16 ? 10L : 9L) * lp.cout * lp.cin, wlo, lp.cout, ep, out, st);
             prof_end();
         } else {
             if (!lp.wpacked) { rc = SR_ERR_STATE; return; }

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
         for (int tap = 0; tap < 9; ++tap) ad[tap] += k * bs[tap];
     }
     const long bstride = 9L * cout * cin;
+    float lo_sum = 0.f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const float* lw = lp.loc_w + (long)(o * 9 + tap) * taps;
@@ -244,8 +245,13 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
         const float hr = 2.0f * sigmoidf(logit);
         const float w = sa[tap] * cf * ad[tap] * hr;
         const long at = b * bstride + ((long)tap * cout + o) * cin + ci;
-        if (sizeof(T) == 2 && f16) {  // one fp16 value per weight (opt-in operand format of the banded conv)
-            ((uint16_t*)wdyn)[at] = f32_to_f16_bits(w);
+        if (sizeof(T) == 2 && f16) {  // one fp16 value per weight (opt-in operand format of the banded conv): [B][10][cout][cin],
+            // plane 9 = the sum over the taps of what the rounding lost (applied to the centre pixel by the conv)
+            const uint16_t hb = f32_to_f16_bits(w);
+            const long at16 = b * (10L * cout * cin) + ((long)tap * cout + o) * cin + ci;
+            ((uint16_t*)wdyn)[at16] = hb;
+            lo_sum += w - (float)__builtin_bit_cast(_Float16, hb);
+            if (tap == 8) ((uint16_t*)wdyn)[b * (10L * cout * cin) + (9L * cout + o) * cin + ci] = f32_to_f16_bits(lo_sum);
             continue;
         }
         Elem<T>::st(wdyn + at, w);
