@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """PSNR delta of the default bf16 path and of the opt-in fp16 operand format over several (weights, input) pairs:
-23-block owner-script networks (seeds), 64 x 64 and 96 x 96 inputs, fp32 oracle on the CPU as the reference.
+23-block owner-script networks (seeds), 64 x 64 and 96 x 96 inputs, fp32 oracle on the CPU as the reference (--ref gpu32: the fp32
+HIP path instead, for 256 x 256 / 512 x 512 inputs).
 
     python tools/diag_f16_pairs.py [--seeds 1,2,3,4,5,6] [--sizes 64,96]
 """
@@ -28,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', default='1,2,3,4,5,6')
     ap.add_argument('--sizes', default='64,96')
+    ap.add_argument('--ref', choices=('oracle', 'gpu32'), default='oracle', help='reference: the fp32 CPU oracle, or the fp32 HIP path (parity-checked against the oracle to 1e-4 in tests/) for sizes the oracle needs minutes for')
     a = ap.parse_args()
     import super_resolution_amd as sra
     from super_resolution_amd import _lib
@@ -41,7 +43,7 @@ def main():
         for size in [int(v) for v in a.sizes.split(',')]:
             x = torch.from_numpy(gp.image_input((1, 1, size, size), 83))
             with torch.no_grad():
-                ref = rrdbnet_forward(sd, x)
+                ref = rrdbnet_forward(sd, x) if a.ref == 'oracle' else net(x.cuda()).cpu()
                 y_def = net(x.cuda().to(torch.bfloat16)).float().cpu()
                 lib.sr_debug_operand_f16(1)
                 try:
