@@ -244,6 +244,9 @@ def run_batch(args, world, rank, dev, dist):
         'config': {'workload': 'RRDBNet-FDConv(1,1,64,23,32) x4 inference, batch %d of %dx%d synthetic grayscale per GPU, '
                                'bf16 (BASELINE.json configs[1])' % (B, H, W),
                    'global_batch': world * B, 'parallelism': 'batch-sharded replicas x%d, no exchange' % world,
+                   'operand_format': 'tensors in HBM bf16; matrix-core operands of the FDConv convs: fp16 (one fp16 weight per MAC + the '
+                                     'summed rounding remainders on the centre tap, activations packed to fp16 by the band-mixing loader), '
+                                     'float32 accumulation; SR_AMD_OPERAND_F16=0: bf16 hi + lo weight pairs with a bf16 operand (secondary.batch_bf16_pair_weights)',
                    'output_finite': finite},
         'roofline': roofline_fields(prof, prof_all, args.steps, float(B) * H * W, 1, traffic_applies=(B, H, W) == (16, 512, 512)),
         'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},
@@ -576,6 +579,7 @@ def main():
     if args.no_split_weights:
         from super_resolution_amd import _lib
         _lib.lib().sr_debug_split_weights(0)
+        _lib.lib().sr_debug_operand_f16(0)
     runners = {'tiled': run_tiled, 'srvgg': run_srvgg, 'batch': run_batch, 'train': run_train}
     res = runners[args.config](args, world, rank, dev, dist)
     if args.config == 'batch' and not args.no_secondary:
@@ -599,17 +603,17 @@ def main():
         threading.Thread(target=watch, daemon=True).start()
         res['secondary'] = {}
         from super_resolution_amd import _lib
-        for name in (('tiled', 'tiled_plain', 'train', 'srvgg', 'batch_f16_operands') if world == 1 else ('tiled', 'tiled_plain', 'train')):
+        for name in (('tiled', 'tiled_plain', 'train', 'srvgg', 'batch_bf16_pair_weights') if world == 1 else ('tiled', 'tiled_plain', 'train')):
             gc.collect()
             torch.cuda.empty_cache()
             a2 = copy.copy(args)
             a2.steps, a2.warmup, a2.no_cpu_baseline = (3 if name == 'srvgg' else 1), 1, True
             a2.plain = name == 'tiled_plain'
             t0 = time.perf_counter()
-            f16 = name == 'batch_f16_operands'  # the headline workload with the opt-in fp16 operand format (DESIGN.md finding 39)
+            f16 = name == 'batch_bf16_pair_weights'  # the headline workload with the operand format of rounds 2-3 (DESIGN.md finding 39)
             try:
                 if f16:
-                    _lib.lib().sr_debug_operand_f16(1)
+                    _lib.lib().sr_debug_operand_f16(0)
                     a2.steps = 3
                 r2 = runners['batch' if f16 else ('tiled' if name == 'tiled_plain' else name)](a2, world, rank, dev, dist)
                 res['secondary'][name] = {'value': r2['value'], 'unit': r2['unit'], 'ms_per_step': r2['ms_per_step'], 'steps': a2.steps,
@@ -618,17 +622,16 @@ def main():
                                           'detail': {k: v for k, v in r2['config'].items() if k not in ('workload',)},
                                           'wall_s': time.perf_counter() - t0}
                 if f16:
-                    res['secondary'][name]['note'] = ('opt-in (SR_AMD_OPERAND_F16=1): one fp16 weight per MAC and an fp16 operand in the FDConv '
-                                                      'convs instead of bf16 hi + lo weights, plus a tenth weight plane (the summed rounding remainders on the centre tap); '
-                                                      'PSNR delta 0.008 dB on the budget test\'s 64x64 pair, 0.007 dB at 512x512 (tests/test_gpu_parity_r2.py), '
-                                                      'worse than the default on one borderline seed of twelve (profiles/r03_k_f16_pairs.txt); NOT the default, not the headline')
+                    res['secondary'][name]['note'] = ('SR_AMD_OPERAND_F16=0: bf16 hi + lo weight pairs with a bf16 operand in the FDConv convs, the format of '
+                                                      'rounds 2-3; the default since the end of round 3 is one fp16 weight per MAC + the summed rounding '
+                                                      'remainders on the centre tap, operand packed to fp16 (DESIGN.md finding 39)')
             except Exception as e:  # a secondary config must never take the headline line down with it
                 res['secondary'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
                 if world > 1:  # the peers may already be inside the next collective: do not join them half-way
                     break
             finally:
                 if f16:
-                    _lib.lib().sr_debug_operand_f16(0)
+                    _lib.lib().sr_debug_operand_f16(1)
         finished.set()
     if rank == 0:
         print(json.dumps(res))

@@ -113,11 +113,13 @@ __device__ __forceinline__ uint32_t modulate2(uint32_t x, uint32_t a, uint32_t b
     r = __builtin_elementwise_fma(c3, unpack2(c), r);
     return pack2(r.x, r.y);
 }
-// fp16 operands (opt-in, DESIGN.md finding 39): the same mix packed to fp16 (v_cvt_pk_f16_f32, round to nearest even; values
-// beyond +-65504 become +-inf as in any fp16 evaluation)
+// fp16 operands (DESIGN.md finding 39): the same mix packed to fp16 (v_cvt_pk_f16_f32, round to nearest even, saturating)
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ uint32_t pack2h(float a, float b) {
+    // saturating: an activation beyond fp16's range becomes +-65504, not inf (bf16 operands have float32's range)
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
     const half2v h = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(uint32_t, h);
 }

@@ -82,9 +82,10 @@ namespace {
 
 // profile groups: head = conv_up1 / conv_up2 / conv_hr / conv_last (the 2x / 4x resolution convs), lowpass_hr = their low-pass launches
 int g_split_weights = 1;  // bf16: dynamic weights as hi + lo pairs (test hook sr_debug_split_weights)
-// opt-in (SR_AMD_OPERAND_F16=1 or sr_debug_operand_f16): the FDConv layers' matrix-core operands in fp16 -- ONE fp16 weight per MAC
-// instead of the bf16 pair, the band-mixed activations packed to fp16 by the loader (DESIGN.md finding 39)
-int g_operand_f16 = getenv("SR_AMD_OPERAND_F16") != nullptr && atoi(getenv("SR_AMD_OPERAND_F16")) != 0;
+// bf16 networks: the FDConv layers' matrix-core operands are fp16 -- ONE fp16 weight per MAC plus the summed rounding remainders as a
+// tenth plane on the centre tap, the band-mixed activations packed to fp16 (saturating) by the loader (DESIGN.md finding 39).
+// SR_AMD_OPERAND_F16=0 (or sr_debug_operand_f16(0)): bf16 hi + lo weight pairs with a bf16 operand, the format of rounds 2-3.
+int g_operand_f16 = !(getenv("SR_AMD_OPERAND_F16") != nullptr && atoi(getenv("SR_AMD_OPERAND_F16")) == 0);
 int g_graphs_on = getenv("SR_AMD_GRAPH") && atoi(getenv("SR_AMD_GRAPH")) != 0;
 
 enum { G_CONV = 0, G_LOWPASS = 1, G_GATES = 2, G_WGEN = 3, G_LAYOUT = 4, G_HEAD = 5, G_LOWPASS_HR = 6, G_NGROUPS = 8 };

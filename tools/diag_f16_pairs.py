@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""PSNR delta of the default bf16 path and of the opt-in fp16 operand format over several (weights, input) pairs:
+"""PSNR delta of the two operand formats of the FDConv convs (bf16 hi + lo weight pairs; fp16 weight + remainder plane, the default)
+over several (weights, input) pairs:
 23-block owner-script networks (seeds), 64 x 64 and 96 x 96 inputs, fp32 oracle on the CPU as the reference (--ref gpu32: the fp32
 HIP path instead, for 256 x 256 / 512 x 512 inputs).
 
@@ -44,17 +45,17 @@ def main():
             x = torch.from_numpy(gp.image_input((1, 1, size, size), 83))
             with torch.no_grad():
                 ref = rrdbnet_forward(sd, x) if a.ref == 'oracle' else net(x.cuda()).cpu()
-                y_def = net(x.cuda().to(torch.bfloat16)).float().cpu()
-                lib.sr_debug_operand_f16(1)
+                lib.sr_debug_operand_f16(0)
                 try:
-                    y_f16 = net(x.cuda().to(torch.bfloat16)).float().cpu()
+                    y_def = net(x.cuda().to(torch.bfloat16)).float().cpu()
                 finally:
-                    lib.sr_debug_operand_f16(0)
+                    lib.sr_debug_operand_f16(1)
+                y_f16 = net(x.cuda().to(torch.bfloat16)).float().cpu()
             lo, hi = ref.min(), ref.max()
             n = lambda v: (v - lo) / (hi - lo)  # noqa: E731
             target = torch.nn.functional.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
             p_ref = psnr(n(ref).clamp(0, 1), target)
-            print('[pairs] seed %d, %dx%d: default delta %.4f dB (direct %.1f dB) | fp16 operands delta %.4f dB (direct %.1f dB)' %
+            print('[pairs] seed %d, %dx%d: bf16 hi + lo pairs delta %.4f dB (direct %.1f dB) | fp16 operands delta %.4f dB (direct %.1f dB)' %
                   (seed, size, size, abs(psnr(n(y_def).clamp(0, 1), target) - p_ref), psnr(n(y_def), n(ref)),
                    abs(psnr(n(y_f16).clamp(0, 1), target) - p_ref), psnr(n(y_f16), n(ref))), flush=True)
 
