@@ -364,6 +364,10 @@ size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet* net, int dtype, int B, int H
 /* x: NCHW (B,num_in_ch,Hin,Win) in io_dtype; y: NCHW (B,num_out_ch,Hin*scale... ) in io_dtype */
 int sr_rrdbnet_forward(sr_rrdbnet* net, int dtype, int io_dtype, int B, int Hin, int Win, const void* x, void* y,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* dtype SR_BF16: the FDConv layers' matrix-core operands are fp16 inside the executor -- one fp16 weight per MAC plus the 9-tap sum of
+ * the rounding remainders on the centre tap, the band-mixed activations packed to fp16 (saturating) -- with float32 accumulation;
+ * SR_AMD_OPERAND_F16=0 in the environment: bf16 hi + lo weight pairs with a bf16 operand (what sr_fdconv_weightgen + sr_conv3x3
+ * compute when called one by one).  Tensors in memory are bf16 either way. */
 /* per-phase kernel-time attribution for bench.py: enables hipEvent timing around kernel groups
  * on the next forward; read back (ms) after a stream sync.  groups (arrays of 8): 0 conv (trunk) 1 lowpass (trunk)
  * 2 gates 3 weightgen 4 layout 5 head convs (conv_up1, conv_up2, conv_hr, conv_last) 6 lowpass of the head tensors
