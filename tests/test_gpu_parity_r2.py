@@ -101,9 +101,11 @@ def test_23_blocks_bf16_psnr_delta_realistic_weights(sra):
     Finding of round 2 (finding 15): on this network ANY evaluation that rounds the per-sample weights to
     bf16 -- the oracle with bf16 operands included -- ends 15-20 dB from the fp32 output, because a rounded weight is an
     error coherent over the whole image and 349 data-dependent layers amplify it; bf16 activations alone cost 50 dB.
-    The conv therefore multiplies by the weights as hi + lo bf16 pairs.  Checked here: (1) the PSNR-delta criterion on
-    the range-normalised output, (2) the direct bf16-vs-fp32 PSNR, (3) that split weights are what buys it (A/B through
-    the debug hook), (4) parity with the oracle's own bf16-storage emulation (same rounding points, hi + lo weights)."""
+    The conv therefore multiplied by the weights as hi + lo bf16 pairs (rounds 2-3) and multiplies, since the end of round 3, by one
+    fp16 weight plus the summed rounding remainders on the centre tap (DESIGN.md finding 39; `net(...)` below runs that default).
+    Checked here: (1) the PSNR-delta criterion on
+    the range-normalised output, (2) the direct bf16-vs-fp32 PSNR, (3) that the extra weight bits are what buys it (A/B through
+    the debug hooks: single bf16 weights), (4) parity with the oracle's own bf16-storage emulation (same rounding points, hi + lo weights)."""
     from super_resolution_amd import _lib
     import oracle.fdconv_ref as fr_mod
     net, sd = realistic_net(sra, (1, 1, 4, 64, 23, 32), seed=2)
