@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_bf16(Concat in, int B, int H
         // the loaders are the pole of the workgroup and, as waves 4-7, lose the age-based issue arbitration against their
         // SIMD partners: static priority for them (A/B: -3.5 % on the Cout = 32 layers, nothing at Cout = 64)
         __builtin_amdgcn_s_setprio(2);
-        constexpr int G = BANDS ? 2 : 5;
+        constexpr int G = BANDS ? 2 : 5;  // (three items per round in the fp16 Cout = 32 kernel, 237 VGPRs, 192 B in flight per lane: +5 % conv time)
         constexpr int ROUNDS = (NPIX * 4 + 256 * G - 1) / (256 * G);
         // SPLIT = 1: rounds ahead of the barrier at which the MFMA waves hand the slab pair back (late, so that the loaders
         // rarely wait for the fused multiply; measured equal to the half-way position: the MFMA waves are the pole there)
